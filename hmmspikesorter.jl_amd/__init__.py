@@ -1,0 +1,20 @@
+"""hmmspikesorter.jl_amd -- MI355X-native HMM spike-sorting hot path (forward/backward/update,
+viterbi, reconstruct_signal of grero/HMMSpikeSorter.jl) behind libhmmsort_hip.so.
+
+The directory name is the one the build contract fixes; it is not a valid Python identifier, so
+import it through the root-level shim:  `import hmmsort_amd`.
+"""
+from . import _lib, synth
+from ._lib import (ENGINE_AUTO, ENGINE_RING, ENGINE_STRICT, HmmsortError, device_count,
+                   get_option, set_option)
+from .api import (HMMSpikeTemplateModel, HMMSpikingModel, StateMatrix, backward, fit, forward,
+                  predict, reconstruct_signal, train_model, train_step, unroll_mlseq, update,
+                  viterbi)
+from .device import Plan
+from .synth import create_signal, create_spike_template
+
+__all__ = ["StateMatrix", "HMMSpikeTemplateModel", "HMMSpikingModel", "forward", "backward",
+           "update", "train_model", "train_step", "viterbi", "reconstruct_signal", "unroll_mlseq",
+           "fit", "predict", "Plan", "create_signal", "create_spike_template", "HmmsortError",
+           "set_option", "get_option", "device_count", "ENGINE_AUTO", "ENGINE_STRICT",
+           "ENGINE_RING"]

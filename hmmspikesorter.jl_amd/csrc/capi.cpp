@@ -1,0 +1,445 @@
+// C ABI of libhmmsort_hip.so (see include/hmmsort.h).  Thin: argument checks, engine choice,
+// device buffers for the host-pointer entry points.  No CPU compute path exists here.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "hmmsort_internal.h"
+
+using namespace hmmsort;
+
+struct hmmsort_plan {
+    HostModel model;
+    int64_t T = 0;
+    int64_t engine = HMMSORT_ENGINE_STRICT;
+    GenericDev *gen = nullptr;
+    RingDev *ring = nullptr;
+};
+
+namespace {
+
+struct DevBuf {  // RAII device buffer for the host-pointer entry points
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        if (hipMalloc(&p, std::max<size_t>(bytes, 8)) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("hipMalloc of %zu bytes failed", bytes);
+            p = nullptr;
+            return HMMSORT_ENOMEM;
+        }
+        return HMMSORT_OK;
+    }
+    template <typename Tv> Tv *as() { return static_cast<Tv *>(p); }
+};
+
+struct PlanGuard {
+    hmmsort_plan *p = nullptr;
+    ~PlanGuard() { if (p) hmmsort_plan_destroy(p); }
+};
+
+int need_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        set_error("no HIP device available (%s); libhmmsort_hip has no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return HMMSORT_EHIP;
+    }
+    return HMMSORT_OK;
+}
+
+int plan_create_engine(hmmsort_plan **out, int64_t T, const int16_t *states, int64_t N, int64_t K,
+                       int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
+                       int64_t engine_req)
+{
+    HS_CHECK(out, HMMSORT_EINVAL, "plan_create: null output pointer");
+    *out = nullptr;
+    HS_CHECK(T >= 1, HMMSORT_EINVAL, "plan_create: T must be >= 1 (got %lld)", (long long)T);
+    int rc = need_device();
+    if (rc) return rc;
+    hmmsort_plan *p = new hmmsort_plan();
+    PlanGuard guard{p};
+    p->T = T;
+    rc = build_host_model(p->model, states, N, K, S, tr, R, mu, sigma);
+    if (rc) return rc;
+    std::string why;
+    const bool ring_ok = ring_supported(p->model, T, &why);
+    if (engine_req == HMMSORT_ENGINE_RING && !ring_ok) {
+        set_error("ring engine unavailable for this model/signal: %s", why.c_str());
+        return HMMSORT_EUNSUP;
+    }
+    if (engine_req != HMMSORT_ENGINE_STRICT && ring_ok) {
+        p->engine = HMMSORT_ENGINE_RING;
+        rc = ring_create(&p->ring, p->model, T);
+    } else {
+        p->engine = HMMSORT_ENGINE_STRICT;
+        rc = generic_create(&p->gen, p->model, T);
+    }
+    if (rc) return rc;
+    guard.p = nullptr;
+    *out = p;
+    return HMMSORT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hmmsort_last_error(void) { return last_error(); }
+int hmmsort_version(void) { return 100; /* 0.1.0 */ }
+
+int hmmsort_device_count(int *count)
+{
+    HS_CHECK(count, HMMSORT_EINVAL, "device_count: null pointer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return HMMSORT_OK;
+}
+
+int hmmsort_set_device(int device)
+{
+    HS_HIP(hipSetDevice(device));
+    return HMMSORT_OK;
+}
+
+int hmmsort_set_option(const char *key, int64_t value)
+{
+    HS_CHECK(key, HMMSORT_EINVAL, "set_option: null key");
+    Options &o = options();
+    if (!strcmp(key, "engine")) {
+        HS_CHECK(value >= 0 && value <= 2, HMMSORT_EINVAL, "set_option: engine must be 0, 1 or 2");
+        o.engine = value;
+    } else if (!strcmp(key, "block")) {
+        HS_CHECK(value >= 0, HMMSORT_EINVAL, "set_option: block must be >= 0");
+        o.block = value;
+    } else if (!strcmp(key, "halo")) {
+        HS_CHECK(value >= 0, HMMSORT_EINVAL, "set_option: halo must be >= 0");
+        o.halo = value;
+    } else {
+        set_error("set_option: unknown key '%s'", key);
+        return HMMSORT_EINVAL;
+    }
+    return HMMSORT_OK;
+}
+
+int hmmsort_get_option(const char *key, int64_t *value)
+{
+    HS_CHECK(key && value, HMMSORT_EINVAL, "get_option: null argument");
+    Options &o = options();
+    if (!strcmp(key, "engine")) *value = o.engine;
+    else if (!strcmp(key, "block")) *value = o.block;
+    else if (!strcmp(key, "halo")) *value = o.halo;
+    else {
+        set_error("get_option: unknown key '%s'", key);
+        return HMMSORT_EINVAL;
+    }
+    return HMMSORT_OK;
+}
+
+int hmmsort_shutdown(void) { return HMMSORT_OK; }
+
+// ---- plan API ------------------------------------------------------------------------------
+
+int hmmsort_plan_create(hmmsort_plan **plan_out, int64_t T, const int16_t *states, int64_t N,
+                        int64_t K, int64_t S, const hmm_trans *tr, int64_t R, const double *mu,
+                        double sigma)
+{
+    return plan_create_engine(plan_out, T, states, N, K, S, tr, R, mu, sigma, options().engine);
+}
+
+int hmmsort_plan_set_model(hmmsort_plan *p, const hmm_trans *tr, int64_t R, const double *mu,
+                           double sigma)
+{
+    HS_CHECK(p && tr && mu, HMMSORT_EINVAL, "plan_set_model: null argument");
+    HS_CHECK(R == p->model.R, HMMSORT_EINVAL, "plan_set_model: R changed (%lld -> %lld)",
+             (long long)p->model.R, (long long)R);
+    HostModel m;
+    std::vector<int16_t> st = p->model.states;
+    int rc = build_host_model(m, st.data(), p->model.N, p->model.K, p->model.S, tr, R, mu, sigma);
+    if (rc) return rc;
+    if (p->engine == HMMSORT_ENGINE_RING) {
+        HS_CHECK(m.ring.valid, HMMSORT_EUNSUP, "plan_set_model: new model is not a ring model");
+        rc = ring_set_model(p->ring, m);
+    } else {
+        rc = generic_set_model(p->gen, m);
+    }
+    if (rc) return rc;
+    p->model = std::move(m);
+    return HMMSORT_OK;
+}
+
+int hmmsort_plan_destroy(hmmsort_plan *p)
+{
+    if (!p) return HMMSORT_OK;
+    if (p->gen) generic_destroy(p->gen);
+    if (p->ring) ring_destroy(p->ring);
+    delete p;
+    return HMMSORT_OK;
+}
+
+int hmmsort_plan_info(const hmmsort_plan *p, int64_t *engine, int64_t *block, int64_t *halo,
+                      int64_t *nchains, int64_t *workspace_bytes)
+{
+    HS_CHECK(p, HMMSORT_EINVAL, "plan_info: null plan");
+    int64_t b = 0, h = 0, n = 0, w = 0;
+    if (p->ring) {
+        ring_geometry(p->ring, &b, &h, &n);
+        w = ring_workspace_bytes(p->ring);
+    } else if (p->gen) {
+        b = p->T; n = 1;
+        w = generic_workspace_bytes(p->gen);
+    }
+    if (engine) *engine = p->engine;
+    if (block) *block = b;
+    if (halo) *halo = h;
+    if (nchains) *nchains = n;
+    if (workspace_bytes) *workspace_bytes = w;
+    return HMMSORT_OK;
+}
+
+int hmmsort_plan_viterbi(hmmsort_plan *p, const double *d_y, int16_t *d_x, double *d_ll,
+                         void *stream)
+{
+    HS_CHECK(p && d_y && d_x && d_ll, HMMSORT_EINVAL, "plan_viterbi: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (p->ring) return ring_viterbi(p->ring, d_y, d_x, d_ll, st);
+    return generic_viterbi(p->gen, d_y, d_x, d_ll, st);
+}
+
+int64_t hmmsort_plan_stats_len(const hmmsort_plan *p)
+{
+    if (!p || !p->ring) return 0;
+    return ring_stats_len(p->ring);
+}
+
+int hmmsort_plan_estep(hmmsort_plan *p, const double *d_y, double *d_stats, void *stream)
+{
+    HS_CHECK(p && d_y && d_stats, HMMSORT_EINVAL, "plan_estep: null argument");
+    HS_CHECK(p->ring, HMMSORT_EUNSUP,
+             "plan_estep: sufficient-statistics E-step needs the ring engine (use hmmsort_em_step)");
+    return ring_estep(p->ring, d_y, d_stats, (hipStream_t)stream);
+}
+
+int hmmsort_plan_mstep(hmmsort_plan *p, const double *d_stats, double *d_out, void *stream)
+{
+    HS_CHECK(p && d_stats && d_out, HMMSORT_EINVAL, "plan_mstep: null argument");
+    HS_CHECK(p->ring, HMMSORT_EUNSUP, "plan_mstep: needs the ring engine");
+    return ring_mstep(p->ring, d_stats, d_out, (hipStream_t)stream);
+}
+
+int hmmsort_plan_diagnostics(hmmsort_plan *p, void *stream, int64_t diag[8])
+{
+    HS_CHECK(p && diag, HMMSORT_EINVAL, "plan_diagnostics: null argument");
+    for (int i = 0; i < 8; i++) diag[i] = 0;
+    if (p->ring) return ring_diagnostics(p->ring, (hipStream_t)stream, diag);
+    return HMMSORT_OK;
+}
+
+// ---- host-buffer entry points --------------------------------------------------------------
+
+int hmmsort_viterbi(const double *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
+                    int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
+                    int16_t *x_out, double *ll_out)
+{
+    HS_CHECK(y && x_out && ll_out, HMMSORT_EINVAL, "viterbi: null argument");
+    HS_CHECK(T >= 1, HMMSORT_EINVAL, "viterbi: empty signal (T = %lld)", (long long)T);
+    PlanGuard pg;
+    int rc = hmmsort_plan_create(&pg.p, T, states, N, K, S, tr, R, mu, sigma);
+    if (rc) return rc;
+    DevBuf dy, dx, dll;
+    if ((rc = dy.alloc(T * sizeof(double))) || (rc = dx.alloc(T * sizeof(int16_t))) ||
+        (rc = dll.alloc(sizeof(double))))
+        return rc;
+    HS_HIP(hipMemcpy(dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
+    rc = hmmsort_plan_viterbi(pg.p, dy.as<double>(), dx.as<int16_t>(), dll.as<double>(), nullptr);
+    if (rc) return rc;
+    HS_HIP(hipDeviceSynchronize());
+    HS_HIP(hipMemcpy(x_out, dx.p, T * sizeof(int16_t), hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(ll_out, dll.p, sizeof(double), hipMemcpyDeviceToHost));
+    return HMMSORT_OK;
+}
+
+static int fwd_bwd_host(bool fwd, const double *y, int64_t T, const int16_t *states, int64_t N,
+                        int64_t K, int64_t S, const hmm_trans *tr, int64_t R, const double *mu,
+                        double sigma, double *out)
+{
+    HS_CHECK(y && out, HMMSORT_EINVAL, "forward/backward: null argument");
+    HS_CHECK(T >= 1, HMMSORT_EINVAL, "forward/backward: empty signal");
+    PlanGuard pg;
+    // materialising S x T output is the generic engine's job whatever the model
+    int rc = plan_create_engine(&pg.p, T, states, N, K, S, tr, R, mu, sigma, HMMSORT_ENGINE_STRICT);
+    if (rc) return rc;
+    DevBuf dy, da;
+    if ((rc = dy.alloc(T * sizeof(double))) || (rc = da.alloc((size_t)S * T * sizeof(double))))
+        return rc;
+    HS_HIP(hipMemcpy(dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
+    rc = fwd ? generic_forward(pg.p->gen, dy.as<double>(), da.as<double>(), nullptr)
+             : generic_backward(pg.p->gen, dy.as<double>(), da.as<double>(), nullptr);
+    if (rc) return rc;
+    HS_HIP(hipDeviceSynchronize());
+    HS_HIP(hipMemcpy(out, da.p, (size_t)S * T * sizeof(double), hipMemcpyDeviceToHost));
+    return HMMSORT_OK;
+}
+
+int hmmsort_forward(const double *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
+                    int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
+                    double *alpha_out)
+{
+    return fwd_bwd_host(true, y, T, states, N, K, S, tr, R, mu, sigma, alpha_out);
+}
+
+int hmmsort_backward(const double *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
+                     int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
+                     double *beta_out)
+{
+    return fwd_bwd_host(false, y, T, states, N, K, S, tr, R, mu, sigma, beta_out);
+}
+
+// unpack [mu K*N | sigma | lp nlp | pp S] from the device into the caller's buffers
+static int unpack_mstep(const double *d_out, int64_t K, int64_t N, int64_t S, int64_t nlp,
+                        double *mu_inout, double *sigma_out, double *lp_out, int64_t lp_cap,
+                        int64_t *n_lp_out, double *pp_out)
+{
+    std::vector<double> h(K * N + 1 + nlp + S);
+    HS_HIP(hipMemcpy(h.data(), d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    memcpy(mu_inout, h.data(), K * N * sizeof(double));
+    *sigma_out = h[K * N];
+    if (n_lp_out) *n_lp_out = nlp;
+    HS_CHECK(lp_cap >= nlp, HMMSORT_EINVAL, "lp_out too small: need %lld entries, got %lld",
+             (long long)nlp, (long long)lp_cap);
+    memcpy(lp_out, h.data() + K * N + 1, nlp * sizeof(double));
+    if (pp_out) memcpy(pp_out, h.data() + K * N + 1 + nlp, S * sizeof(double));
+    return HMMSORT_OK;
+}
+
+int hmmsort_update(const double *alpha, const double *beta, const double *x, int64_t T,
+                   const int16_t *states, int64_t N, int64_t K, int64_t S, const hmm_trans *tr,
+                   int64_t R, double *mu_inout, double sigma, double *sigma_out, double *lp_out,
+                   int64_t lp_cap, int64_t *n_lp_out, double *pp_out)
+{
+    HS_CHECK(alpha && beta && x && mu_inout && sigma_out && lp_out, HMMSORT_EINVAL,
+             "update: null argument");
+    HS_CHECK(T >= 2, HMMSORT_EINVAL, "update: need T >= 2");
+    PlanGuard pg;
+    int rc = plan_create_engine(&pg.p, T, states, N, K, S, tr, R, mu_inout, sigma,
+                                HMMSORT_ENGINE_STRICT);
+    if (rc) return rc;
+    const int64_t nlp = generic_n_lp(pg.p->gen);
+    DevBuf dy, da, db, dout;
+    const size_t st = (size_t)S * T * sizeof(double);
+    if ((rc = dy.alloc(T * sizeof(double))) || (rc = da.alloc(st)) || (rc = db.alloc(st)) ||
+        (rc = dout.alloc((K * N + 1 + nlp + S) * sizeof(double))))
+        return rc;
+    HS_HIP(hipMemcpy(dy.p, x, T * sizeof(double), hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(da.p, alpha, st, hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(db.p, beta, st, hipMemcpyHostToDevice));
+    rc = generic_update(pg.p->gen, da.as<double>(), db.as<double>(), dy.as<double>(),
+                        dout.as<double>(), nullptr);
+    if (rc) return rc;
+    HS_HIP(hipDeviceSynchronize());
+    return unpack_mstep(dout.as<double>(), K, N, S, nlp, mu_inout, sigma_out, lp_out, lp_cap,
+                        n_lp_out, pp_out);
+}
+
+int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
+                    int64_t S, const hmm_trans *tr, int64_t R, double *mu_inout, double sigma,
+                    double *sigma_out, double *lp_out, int64_t lp_cap, int64_t *n_lp_out,
+                    double *pp_out)
+{
+    HS_CHECK(y && mu_inout && sigma_out && lp_out, HMMSORT_EINVAL, "em_step: null argument");
+    HS_CHECK(T >= 2, HMMSORT_EINVAL, "em_step: need T >= 2");
+    PlanGuard pg;
+    int rc = hmmsort_plan_create(&pg.p, T, states, N, K, S, tr, R, mu_inout, sigma);
+    if (rc) return rc;
+    DevBuf dy;
+    if ((rc = dy.alloc(T * sizeof(double)))) return rc;
+    HS_HIP(hipMemcpy(dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
+    if (pg.p->ring) {
+        const int64_t nlp = N;
+        DevBuf dstats, dout;
+        if ((rc = dstats.alloc(ring_stats_len(pg.p->ring) * sizeof(double))) ||
+            (rc = dout.alloc((K * N + 1 + nlp + S) * sizeof(double))))
+            return rc;
+        if ((rc = ring_estep(pg.p->ring, dy.as<double>(), dstats.as<double>(), nullptr))) return rc;
+        if ((rc = ring_mstep(pg.p->ring, dstats.as<double>(), dout.as<double>(), nullptr))) return rc;
+        HS_HIP(hipDeviceSynchronize());
+        return unpack_mstep(dout.as<double>(), K, N, S, nlp, mu_inout, sigma_out, lp_out, lp_cap,
+                            n_lp_out, pp_out);
+    }
+    // generic engine: forward -> backward -> update with materialised alpha/beta, all on device
+    const int64_t nlp = generic_n_lp(pg.p->gen);
+    DevBuf da, db, dout;
+    const size_t st = (size_t)S * T * sizeof(double);
+    if ((rc = da.alloc(st)) || (rc = db.alloc(st)) ||
+        (rc = dout.alloc((K * N + 1 + nlp + S) * sizeof(double))))
+        return rc;
+    if ((rc = generic_forward(pg.p->gen, dy.as<double>(), da.as<double>(), nullptr))) return rc;
+    if ((rc = generic_backward(pg.p->gen, dy.as<double>(), db.as<double>(), nullptr))) return rc;
+    if ((rc = generic_update(pg.p->gen, da.as<double>(), db.as<double>(), dy.as<double>(),
+                             dout.as<double>(), nullptr)))
+        return rc;
+    HS_HIP(hipDeviceSynchronize());
+    return unpack_mstep(dout.as<double>(), K, N, S, nlp, mu_inout, sigma_out, lp_out, lp_cap,
+                        n_lp_out, pp_out);
+}
+
+int hmmsort_reconstruct(const int16_t *x, int64_t T, const int16_t *states, int64_t N, int64_t S,
+                        const double *mu, int64_t K, double *y_out)
+{
+    HS_CHECK(states && mu && (T == 0 || (x && y_out)), HMMSORT_EINVAL, "reconstruct: null argument");
+    HS_CHECK(T >= 0 && N >= 1 && S >= 1 && K >= 1, HMMSORT_EINVAL, "reconstruct: bad sizes");
+    if (T == 0) return HMMSORT_OK;  // reference returns an empty vector
+    int rc = need_device();
+    if (rc) return rc;
+    for (int64_t i = 0; i < T; i++)
+        HS_CHECK(x[i] >= 1 && x[i] <= S, HMMSORT_EINVAL,
+                 "reconstruct: x[%lld] = %d outside 1..S (reference would throw BoundsError)",
+                 (long long)i, (int)x[i]);
+    DevBuf dx, dst, dmu, dout;
+    if ((rc = dx.alloc(T * sizeof(int16_t))) || (rc = dst.alloc(N * S * sizeof(int16_t))) ||
+        (rc = dmu.alloc(K * N * sizeof(double))) || (rc = dout.alloc(T * sizeof(double))))
+        return rc;
+    HS_HIP(hipMemcpy(dx.p, x, T * sizeof(int16_t), hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(dst.p, states, N * S * sizeof(int16_t), hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(dmu.p, mu, K * N * sizeof(double), hipMemcpyHostToDevice));
+    rc = dev_reconstruct(dx.as<int16_t>(), T, dst.as<int16_t>(), N, S, dmu.as<double>(), K,
+                         dout.as<double>(), nullptr);
+    if (rc) return rc;
+    HS_HIP(hipDeviceSynchronize());
+    HS_HIP(hipMemcpy(y_out, dout.p, T * sizeof(double), hipMemcpyDeviceToHost));
+    return HMMSORT_OK;
+}
+
+int hmmsort_unroll_mlseq(const int16_t *mlseq, int64_t T, const int16_t *states, int64_t N,
+                         int64_t S, int16_t *out)
+{
+    HS_CHECK(states && (T == 0 || (mlseq && out)), HMMSORT_EINVAL, "unroll_mlseq: null argument");
+    if (T == 0) return HMMSORT_OK;
+    int rc = need_device();
+    if (rc) return rc;
+    for (int64_t i = 0; i < T; i++)
+        HS_CHECK(mlseq[i] >= 1 && mlseq[i] <= S, HMMSORT_EINVAL,
+                 "unroll_mlseq: mlseq[%lld] = %d outside 1..S", (long long)i, (int)mlseq[i]);
+    DevBuf dx, dst, dout;
+    if ((rc = dx.alloc(T * sizeof(int16_t))) || (rc = dst.alloc(N * S * sizeof(int16_t))) ||
+        (rc = dout.alloc((size_t)N * T * sizeof(int16_t))))
+        return rc;
+    HS_HIP(hipMemcpy(dx.p, mlseq, T * sizeof(int16_t), hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(dst.p, states, N * S * sizeof(int16_t), hipMemcpyHostToDevice));
+    rc = dev_unroll(dx.as<int16_t>(), T, dst.as<int16_t>(), N, S, dout.as<int16_t>(), nullptr);
+    if (rc) return rc;
+    HS_HIP(hipDeviceSynchronize());
+    HS_HIP(hipMemcpy(out, dout.p, (size_t)N * T * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return HMMSORT_OK;
+}
+
+}  // extern "C"

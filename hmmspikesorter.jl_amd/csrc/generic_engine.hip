@@ -1,0 +1,417 @@
+// Generic ("strict") engine: one sequential sweep per signal over an ARBITRARY transition list
+// (overlap models included), in the reference's operation order.
+//
+//   viterbi  : reference src/viterbi.jl:44-98   -- bit-exact path and ll by construction
+//              (same fp64 operations in the same order; only + - * / > are used in the loop)
+//   forward  : reference src/baumwelch.jl:25-51 -- same fold order; exp/log1p are ROCm's
+//   backward : reference src/baumwelch.jl:73-98
+//
+// One workgroup owns the whole state vector: delta/alpha live in LDS (two S-vectors, ping-pong),
+// one barrier per sample.  The kernels are latency-bound by design; they exist for API parity on
+// short signals, for overlap models, and as the on-GPU bit-exact check of the ring engine.
+// Compiled with -ffp-contract=off (Julia does not contract).
+#include <cmath>
+#include <cstdio>
+
+#include "generic_dev.h"
+#include "hmmsort_internal.h"
+
+namespace hmmsort {
+
+// ------------------------------------------------------------------------------------------
+// device math restating reference utils.jl
+// ------------------------------------------------------------------------------------------
+// funcl(x, mu, sigma, lsigma) utils.jl:4 with the loop-invariant parts hoisted (same values):
+//   c0 = -log2pi - lsigma,  den = 2*sigma^2,  result = c0 - (dd*dd)/den
+__device__ __forceinline__ double funcl_dev(double x, double mu, double c0, double den)
+{
+    double dd = x - mu;
+    return c0 - (dd * dd) / den;
+}
+
+// logsumexpl(xp, yp) utils.jl:24-32
+__device__ __forceinline__ double logsumexpl_dev(double xp, double yp)
+{
+    if (xp > yp) return xp + log1p(exp(yp - xp));
+    return yp + log1p(exp(xp - yp));
+}
+
+// ------------------------------------------------------------------------------------------
+// Viterbi forward sweep.  grid = 1 block.  LDS: 2*S doubles.
+// ------------------------------------------------------------------------------------------
+__global__ void gen_viterbi_sweep(const double *__restrict__ y, int64_t T, int S,
+                                  const double *__restrict__ mean,
+                                  const int32_t *__restrict__ in_ptr,
+                                  const int32_t *__restrict__ in_src,
+                                  const double *__restrict__ in_lp, double c0, double den,
+                                  int16_t *__restrict__ T2, double *__restrict__ last)
+{
+    extern __shared__ double sh[];
+    double *prev = sh, *cur = sh + S;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // viterbi.jl:55-63  first column: emission only, then T1[1,1] = 0
+    {
+        const double y0 = y[0];
+        for (int j = tid; j < S; j += nt) {
+            cur[j] = (j == 0) ? 0.0 : funcl_dev(y0, mean[j], c0, den);
+            T2[j] = 1;
+        }
+    }
+    for (int64_t t = 1; t < T; t++) {
+        __syncthreads();
+        double *tmp = prev; prev = cur; cur = tmp;
+        const double yt = y[t];
+        int16_t *psi = T2 + (int64_t)S * t;
+        for (int j = tid; j < S; j += nt) {
+            double best = -INFINITY;  // viterbi.jl:52 fill(-Inf)
+            int arg = 1;              // viterbi.jl:53 ones(Int16)
+            const int e1 = in_ptr[j + 1];
+            for (int e = in_ptr[j]; e < e1; e++) {  // list order == source ascending
+                double tt = prev[in_src[e]] + in_lp[e];  // :79
+                if (tt > best) {                           // :80 strict
+                    best = tt;
+                    arg = in_src[e] + 1;
+                }
+            }
+            cur[j] = best + funcl_dev(yt, mean[j], c0, den);  // :85-87
+            psi[j] = (int16_t)arg;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < S; j += nt) last[j] = cur[j];
+}
+
+// argmax (first maximum, viterbi.jl:90) + backtrace (:93-94).  One block; T2 columns are staged
+// through LDS in coalesced bulk so the serial walk never waits on HBM.
+__global__ void gen_viterbi_backtrace(const int16_t *__restrict__ T2, const double *__restrict__ last,
+                                      int64_t T, int S, int W, int16_t *__restrict__ x)
+{
+    extern __shared__ int16_t shp[];  // W columns of S entries
+    __shared__ int cur_state;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) {
+        int best = 0;
+        for (int j = 1; j < S; j++)
+            if (last[j] > last[best]) best = j;
+        cur_state = best + 1;
+        x[T - 1] = (int16_t)(best + 1);
+    }
+    // walk i = T-1 .. 1 in chunks [lo, hi]
+    for (int64_t hi = T - 1; hi >= 1; hi -= W) {
+        int64_t lo = hi - W + 1;
+        if (lo < 1) lo = 1;
+        const int64_t ncol = hi - lo + 1;
+        __syncthreads();
+        const int64_t nel = ncol * S;
+        const int16_t *srcp = T2 + (int64_t)S * lo;
+        for (int64_t e = tid; e < nel; e += nt) shp[e] = srcp[e];
+        __syncthreads();
+        if (tid == 0) {
+            int xs = cur_state;
+            for (int64_t i = hi; i >= lo; i--) {
+                xs = shp[(i - lo) * S + (xs - 1)];
+                x[i - 1] = (int16_t)xs;
+            }
+            cur_state = xs;
+        }
+    }
+}
+
+// Path values T1[x[t],t] re-accumulated along the decoded path with the reference's op order
+// ((T1[k]+lp)+q), then ll summed from i = nobs down to 2 (viterbi.jl:92-96).  One thread.
+__global__ void gen_viterbi_ll(const double *__restrict__ y, const int16_t *__restrict__ x,
+                               int64_t T, const double *__restrict__ mean,
+                               const int32_t *__restrict__ in_ptr,
+                               const int32_t *__restrict__ in_src,
+                               const double *__restrict__ in_lp, double c0, double den,
+                               double *__restrict__ pv, double *__restrict__ ll_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int xp = x[0] - 1;
+    double p = (xp == 0) ? 0.0 : funcl_dev(y[0], mean[xp], c0, den);
+    pv[0] = p;
+    for (int64_t t = 1; t < T; t++) {
+        const int xc = x[t] - 1;
+        double lp = -INFINITY;
+        const int e1 = in_ptr[xc + 1];
+        for (int e = in_ptr[xc]; e < e1; e++)
+            if (in_src[e] == xp) { lp = in_lp[e]; break; }
+        p = (p + lp) + funcl_dev(y[t], mean[xc], c0, den);
+        pv[t] = p;
+        xp = xc;
+    }
+    double ll = 0.0;
+    for (int64_t i = T - 1; i >= 1; i--) ll += pv[i];
+    *ll_out = ll;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / backward (materialising, S x T column-major like the reference)
+// ------------------------------------------------------------------------------------------
+__global__ void gen_forward_sweep(const double *__restrict__ y, int64_t T, int S,
+                                  const double *__restrict__ mean,
+                                  const int32_t *__restrict__ in_ptr,
+                                  const int32_t *__restrict__ in_src,
+                                  const double *__restrict__ in_lp, double c0, double den,
+                                  double *__restrict__ alpha)
+{
+    extern __shared__ double sh[];
+    double *prev = sh, *cur = sh + S;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    {
+        const double y0 = y[0];
+        for (int j = tid; j < S; j += nt) {  // baumwelch.jl:36
+            double v = funcl_dev(y0, mean[j], c0, den);
+            cur[j] = v;
+            alpha[j] = v;
+        }
+    }
+    for (int64_t t = 1; t < T; t++) {
+        __syncthreads();
+        double *tmp = prev; prev = cur; cur = tmp;
+        const double yt = y[t];
+        double *at = alpha + (int64_t)S * t;
+        for (int j = tid; j < S; j += nt) {
+            const double b = funcl_dev(yt, mean[j], c0, den);
+            double acc = -INFINITY;  // :28 fill(-Inf)
+            const int e1 = in_ptr[j + 1];
+            for (int e = in_ptr[j]; e < e1; e++)
+                acc = logsumexpl_dev(acc, (prev[in_src[e]] + in_lp[e]) + b);  // :47
+            cur[j] = acc;
+            at[j] = acc;
+        }
+    }
+}
+
+__global__ void gen_backward_sweep(const double *__restrict__ y, int64_t T, int S,
+                                   const double *__restrict__ mean,
+                                   const int32_t *__restrict__ out_ptr,
+                                   const int32_t *__restrict__ out_dst,
+                                   const double *__restrict__ out_lp, double c0, double den,
+                                   double *__restrict__ beta)
+{
+    extern __shared__ double sh[];
+    double *nxt = sh, *cur = sh + S, *bq = sh + 2 * S;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int j = tid; j < S; j += nt) {  // baumwelch.jl:80
+        cur[j] = 0.0;
+        beta[j + (int64_t)S * (T - 1)] = 0.0;
+    }
+    for (int64_t t = T - 2; t >= 0; t--) {
+        __syncthreads();
+        double *tmp = nxt; nxt = cur; cur = tmp;
+        const double v = y[t + 1];
+        for (int j = tid; j < S; j += nt) bq[j] = funcl_dev(v, mean[j], c0, den);
+        __syncthreads();
+        double *bt = beta + (int64_t)S * t;
+        for (int j = tid; j < S; j += nt) {
+            double acc = -INFINITY;  // :79
+            const int e1 = out_ptr[j + 1];
+            for (int e = out_ptr[j]; e < e1; e++) {
+                const int k = out_dst[e];
+                acc = logsumexpl_dev(acc, (nxt[k] + out_lp[e]) + bq[k]);  // :94
+            }
+            cur[j] = acc;
+            bt[j] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// reconstruct_signal (reconstruction.jl:1-10) and unroll_mlseq (extraction.jl:4-13)
+// ------------------------------------------------------------------------------------------
+__global__ void k_reconstruct(const int16_t *__restrict__ x, int64_t T,
+                              const int16_t *__restrict__ states, int N, int S,
+                              const double *__restrict__ mu, int K, double *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < T; i += stride) {
+        int xs = x[i];
+        double a = 0.0;
+        if (xs >= 1 && xs <= S)
+            for (int j = 0; j < N; j++) a += mu[(states[j + N * (xs - 1)] - 1) + K * j];
+        else
+            a = NAN;
+        out[i] = a;
+    }
+}
+
+__global__ void k_unroll(const int16_t *__restrict__ x, int64_t T,
+                         const int16_t *__restrict__ states, int N, int S,
+                         int16_t *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < T; i += stride) {
+        int xs = x[i];
+        for (int j = 0; j < N; j++)
+            out[j + (int64_t)N * i] = (xs >= 1 && xs <= S) ? states[j + N * (xs - 1)] : (int16_t)0;
+    }
+}
+
+int dev_reconstruct(const int16_t *d_x, int64_t T, const int16_t *d_states, int64_t N, int64_t S,
+                    const double *d_mu, int64_t K, double *d_out, hipStream_t st)
+{
+    if (T <= 0) return HMMSORT_OK;
+    int blocks = (int)std::min<int64_t>((T + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_reconstruct, dim3(blocks), dim3(256), 0, st, d_x, T, d_states, (int)N,
+                       (int)S, d_mu, (int)K, d_out);
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+int dev_unroll(const int16_t *d_x, int64_t T, const int16_t *d_states, int64_t N, int64_t S,
+               int16_t *d_out, hipStream_t st)
+{
+    if (T <= 0) return HMMSORT_OK;
+    int blocks = (int)std::min<int64_t>((T + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_unroll, dim3(blocks), dim3(256), 0, st, d_x, T, d_states, (int)N, (int)S,
+                       d_out);
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+template <typename Tv>
+static int upload(Tv **dst, const std::vector<Tv> &v, int64_t *bytes)
+{
+    if (!*dst) {
+        HS_HIP(hipMalloc((void **)dst, std::max<size_t>(v.size(), 1) * sizeof(Tv)));
+        *bytes += v.size() * sizeof(Tv);
+    }
+    if (!v.empty()) HS_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(Tv), hipMemcpyHostToDevice));
+    return HMMSORT_OK;
+}
+
+int generic_set_model(GenericDev *g, const HostModel &m)
+{
+    HS_CHECK(m.N == g->N && m.K == g->K && m.S == g->S && m.R == g->R, HMMSORT_EINVAL,
+             "set_model: model shape changed");
+    g->sigma = m.sigma;
+    g->lsig = std::log(m.sigma);  // viterbi.jl:47, on the host so it equals the CPU value
+    int rc;
+    if ((rc = upload(&g->d_mean, m.mean, &g->bytes))) return rc;
+    if ((rc = upload(&g->d_in_ptr, m.in_ptr, &g->bytes))) return rc;
+    if ((rc = upload(&g->d_in_src, m.in_src, &g->bytes))) return rc;
+    if ((rc = upload(&g->d_in_lp, m.in_lp, &g->bytes))) return rc;
+    if ((rc = upload(&g->d_out_ptr, m.out_ptr, &g->bytes))) return rc;
+    if ((rc = upload(&g->d_out_dst, m.out_dst, &g->bytes))) return rc;
+    if ((rc = upload(&g->d_out_lp, m.out_lp, &g->bytes))) return rc;
+    if ((rc = upload(&g->d_mu, m.mu, &g->bytes))) return rc;
+    if ((rc = upload(&g->d_states, m.states, &g->bytes))) return rc;
+    g->nsrc1 = m.out_ptr[1] - m.out_ptr[0];
+    return HMMSORT_OK;
+}
+
+int generic_create(GenericDev **out, const HostModel &m, int64_t T)
+{
+    HS_CHECK(T >= 1, HMMSORT_EINVAL, "generic engine: T must be >= 1");
+    // LDS budget: 3*S doubles (backward) must fit 160 KiB
+    HS_CHECK(3 * m.S * 8 <= 160 * 1024, HMMSORT_EUNSUP,
+             "generic engine: %lld states do not fit LDS (max %d)", (long long)m.S,
+             160 * 1024 / 24);
+    GenericDev *g = new GenericDev();
+    g->N = m.N; g->K = m.K; g->S = m.S; g->R = m.R; g->T = T;
+    int th = (int)((m.S + 63) / 64 * 64);
+    g->threads = th < 64 ? 64 : (th > 1024 ? 1024 : th);
+    int rc = generic_set_model(g, m);
+    if (rc) { generic_destroy(g); return rc; }
+    if (hipMalloc((void **)&g->d_last, m.S * sizeof(double)) != hipSuccess) {
+        set_error("generic engine: hipMalloc failed");
+        generic_destroy(g);
+        return HMMSORT_ENOMEM;
+    }
+    g->bytes += m.S * sizeof(double);
+    *out = g;
+    return HMMSORT_OK;
+}
+
+void generic_destroy(GenericDev *g)
+{
+    if (!g) return;
+    void *ptrs[] = {g->d_mean, g->d_in_lp, g->d_out_lp, g->d_mu, g->d_in_ptr, g->d_in_src,
+                    g->d_out_ptr, g->d_out_dst, g->d_states, g->d_T2, g->d_pv, g->d_last,
+                    g->d_upd};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete g;
+}
+
+int64_t generic_workspace_bytes(const GenericDev *g) { return g->bytes; }
+int64_t generic_n_lp(const GenericDev *g) { return g->nsrc1 - 1; }
+
+static int set_lds_limit(const void *fn, size_t bytes)
+{
+    if (bytes > 64 * 1024)
+        HS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return HMMSORT_OK;
+}
+
+int generic_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st)
+{
+    const int64_t T = g->T, S = g->S;
+    if (!g->d_T2) {
+        const double need = (double)S * (double)T * 2.0 + (double)T * 8.0;
+        HS_CHECK(need < 200e9, HMMSORT_ENOMEM,
+                 "strict Viterbi needs %.1f GB of back-pointers; decode in chunks", need / 1e9);
+        if (hipMalloc((void **)&g->d_T2, (size_t)S * T * sizeof(int16_t)) != hipSuccess ||
+            hipMalloc((void **)&g->d_pv, (size_t)T * sizeof(double)) != hipSuccess) {
+            set_error("strict Viterbi: hipMalloc of %.1f GB failed", need / 1e9);
+            return HMMSORT_ENOMEM;
+        }
+        g->bytes += (int64_t)need;
+    }
+    const double c0 = -kLog2Pi - g->lsig;
+    const double den = 2.0 * (g->sigma * g->sigma);
+    size_t lds = 2 * S * sizeof(double);
+    int rc = set_lds_limit((const void *)gen_viterbi_sweep, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gen_viterbi_sweep, dim3(1), dim3(g->threads), lds, st, d_y, T, (int)S,
+                       g->d_mean, g->d_in_ptr, g->d_in_src, g->d_in_lp, c0, den, g->d_T2,
+                       g->d_last);
+    HS_HIP(hipGetLastError());
+    int W = (int)std::max<int64_t>(1, (48 * 1024) / (S * 2));
+    size_t lds2 = (size_t)W * S * sizeof(int16_t);
+    rc = set_lds_limit((const void *)gen_viterbi_backtrace, lds2);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gen_viterbi_backtrace, dim3(1), dim3(256), lds2, st, g->d_T2, g->d_last, T,
+                       (int)S, W, d_x);
+    HS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(gen_viterbi_ll, dim3(1), dim3(64), 0, st, d_y, d_x, T, g->d_mean,
+                       g->d_in_ptr, g->d_in_src, g->d_in_lp, c0, den, g->d_pv, d_ll);
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+int generic_forward(GenericDev *g, const double *d_y, double *d_alpha, hipStream_t st)
+{
+    // funcl 3-arg form (utils.jl:3): -log2pi - log(sigma) - ...; same constant as the 4-arg form
+    const double c0 = -kLog2Pi - g->lsig;
+    const double den = 2.0 * (g->sigma * g->sigma);
+    size_t lds = 2 * g->S * sizeof(double);
+    int rc = set_lds_limit((const void *)gen_forward_sweep, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gen_forward_sweep, dim3(1), dim3(g->threads), lds, st, d_y, g->T, (int)g->S,
+                       g->d_mean, g->d_in_ptr, g->d_in_src, g->d_in_lp, c0, den, d_alpha);
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+int generic_backward(GenericDev *g, const double *d_y, double *d_beta, hipStream_t st)
+{
+    const double c0 = -kLog2Pi - g->lsig;
+    const double den = 2.0 * (g->sigma * g->sigma);
+    size_t lds = 3 * g->S * sizeof(double);
+    int rc = set_lds_limit((const void *)gen_backward_sweep, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gen_backward_sweep, dim3(1), dim3(g->threads), lds, st, d_y, g->T,
+                       (int)g->S, g->d_mean, g->d_out_ptr, g->d_out_dst, g->d_out_lp, c0, den,
+                       d_beta);
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+}  // namespace hmmsort

@@ -1,0 +1,72 @@
+"""Device-resident plan API (hmmsort_plan_* in include/hmmsort.h) for hosts that keep the signal
+in HBM: bench.py and the multi-GPU driver.  Buffers are plain device pointers; torch is used only
+as the allocator/stream provider (tensor.data_ptr(), torch.cuda.current_stream().cuda_stream)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import TRANS_DTYPE, check, lib, ptr
+
+
+def _dptr(t):
+    """device pointer of a torch tensor (or an int that already is one)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+class Plan:
+    """One recording channel of length T with a fixed model shape."""
+
+    def __init__(self, T, lA, mu, sigma):
+        self._h = C.c_void_p(None)
+        self.T = int(T)
+        self.lA = lA
+        mu = np.asfortranarray(mu, dtype=np.float64)
+        tr = np.ascontiguousarray(lA.transitions, dtype=TRANS_DTYPE)
+        st = np.asfortranarray(lA.states, dtype=np.int16)
+        check(lib().hmmsort_plan_create(C.byref(self._h), self.T, ptr(st), lA.N, lA.K, lA.nstates,
+                                        ptr(tr), len(tr), ptr(mu), float(sigma)))
+        self.K, self.N, self.S = lA.K, lA.N, lA.nstates
+
+    def close(self):
+        if self._h:
+            lib().hmmsort_plan_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    __del__ = close
+
+    def info(self):
+        v = [C.c_int64(0) for _ in range(5)]
+        check(lib().hmmsort_plan_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("engine", "block", "halo", "nchains", "workspace_bytes"),
+                        [x.value for x in v]))
+
+    def set_model(self, lA, mu, sigma):
+        mu = np.asfortranarray(mu, dtype=np.float64)
+        tr = np.ascontiguousarray(lA.transitions, dtype=TRANS_DTYPE)
+        check(lib().hmmsort_plan_set_model(self._h, ptr(tr), len(tr), ptr(mu), float(sigma)))
+        self.lA = lA
+
+    def viterbi(self, d_y, d_x, d_ll, stream=0):
+        check(lib().hmmsort_plan_viterbi(self._h, _dptr(d_y), _dptr(d_x), _dptr(d_ll),
+                                         C.c_void_p(stream)))
+
+    def stats_len(self):
+        return int(lib().hmmsort_plan_stats_len(self._h))
+
+    def mstep_len(self):
+        return self.K * self.N + 1 + self.N + self.S
+
+    def estep(self, d_y, d_stats, stream=0):
+        check(lib().hmmsort_plan_estep(self._h, _dptr(d_y), _dptr(d_stats), C.c_void_p(stream)))
+
+    def mstep(self, d_stats, d_out, stream=0):
+        check(lib().hmmsort_plan_mstep(self._h, _dptr(d_stats), _dptr(d_out), C.c_void_p(stream)))
+
+    def diagnostics(self, stream=0):
+        d = (C.c_int64 * 8)()
+        check(lib().hmmsort_plan_diagnostics(self._h, C.c_void_p(stream), d))
+        return list(d)

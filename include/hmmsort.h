@@ -1,0 +1,169 @@
+/*
+ * hmmsort.h -- C ABI of libhmmsort_hip.so: the MI355X (gfx950) implementation of the HMM hot
+ * path of grero/HMMSpikeSorter.jl (forward/backward/update, viterbi, reconstruct_signal).
+ *
+ * The reference (Julia) has NO FFI on this path (no ccall anywhere in /root/reference); the
+ * boundary is therefore placed at the narrowest existing seam: the Julia methods listed
+ * below.  A drop-in keeps their signatures and replaces their bodies by one ccall each
+ * (julia/HMMSpikeSorterHIP.jl).  Each entry point cites the reference method
+ * it replaces as file:line relative to the reference repository root.
+ *
+ * Conventions (all inherited from the reference so Julia arrays can be passed as they are):
+ *   - matrices are column-major; state ids and transition endpoints are 1-based;
+ *   - `states` is the N x S Int16 matrix StateMatrix.states (types.jl:2): entry = row of mu,
+ *     1 = silent;
+ *   - `tr` is StateMatrix.transitions (types.jl:3): a Vector{Tuple{Int64,Int64,Float64}} is a
+ *     contiguous array of 24-byte isbits tuples == struct hmm_trans, in the reference's order
+ *     (source-major, destination ascending, types.jl:115-127).  The order is part of the
+ *     contract: it fixes Viterbi tie-breaking and log-sum-exp fold order;
+ *   - mu is K x N (baumwelch.jl:314); StateMatrix.pi is never read on this path and is not
+ *     passed;
+ *   - all buffers are owned by the caller; the library reads/writes them only during the call;
+ *   - every function returns 0 on success or a negative HMMSORT_E* code and never throws;
+ *     hmmsort_last_error() returns a thread-local message for the last failure;
+ *   - calls are synchronous (they return after the GPU work and the copy-back finished).
+ *     The library is safe to call from several host threads (per-call streams/workspaces).
+ *
+ * There is no CPU fallback: without a HIP device every compute entry point fails with
+ * HMMSORT_EHIP.
+ */
+#ifndef HMMSORT_H
+#define HMMSORT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMMSORT_OK 0
+#define HMMSORT_EINVAL (-1)  /* bad argument / inconsistent model */
+#define HMMSORT_ENOMEM (-2)  /* host or device allocation failed / problem too large */
+#define HMMSORT_EHIP (-3)    /* HIP runtime error (includes: no device) */
+#define HMMSORT_ENOCONV (-4) /* time-parallel engine could not certify its block boundaries */
+#define HMMSORT_EUNSUP (-5)  /* model shape not supported by the requested engine */
+
+/* Julia Tuple{Int64,Int64,Float64}  (types.jl:3) */
+typedef struct hmm_trans {
+    int64_t src;
+    int64_t dst;
+    double lp;
+} hmm_trans;
+
+/* engine selection for hmmsort_set_option("engine", ...) */
+#define HMMSORT_ENGINE_AUTO 0   /* ring engine when the model is a no-overlap ring model and
+                                   T is long enough, else the generic engine */
+#define HMMSORT_ENGINE_STRICT 1 /* generic engine: one sequential sweep per signal in the
+                                   reference's operation order (bit-exact Viterbi incl. ll) */
+#define HMMSORT_ENGINE_RING 2   /* time-parallel ring engine or fail with HMMSORT_EUNSUP */
+
+const char *hmmsort_last_error(void);
+int hmmsort_version(void);
+int hmmsort_device_count(int *count);
+int hmmsort_set_device(int device);
+/* keys: "engine" (above), "block" (ring engine time-block length, 0 = auto),
+ *       "halo" (ring engine warm-up length, 0 = auto).  Process-wide defaults. */
+int hmmsort_set_option(const char *key, int64_t value);
+int hmmsort_get_option(const char *key, int64_t *value);
+int hmmsort_shutdown(void);
+
+/* ---- state space helpers (host side, no GPU needed) ------------------------------------ */
+
+/* generate_states(N,K,allow_overlaps) .+ 1   (types.jl:65-92,150).  states_out is N x S Int16
+ * (1-based rows of mu) or NULL to query S only.  Returns S (>0) or a negative error. */
+int64_t hmmsort_generate_states(int64_t N, int64_t K, int allow_overlaps, int16_t *states_out);
+
+/* get_valid_transitions(states, K, lp)  (types.jl:94-127) in closed form: O(R) instead of the
+ * reference's O(S^2 N) all-pairs scan, emitting the SAME list in the SAME order with the same
+ * floating-point values (log-probabilities are accumulated neuron by neuron exactly as
+ * isvalid_transition does).  tr_out may be NULL to query the count.  Returns R or <0.
+ * Replaces the rebuild `StateMatrix(states.-1, pp, K, xb[2:end])` of baumwelch.jl:265. */
+int64_t hmmsort_build_transitions(int64_t N, int64_t K, const double *lp, int64_t nlp,
+                                  int allow_overlaps, hmm_trans *tr_out, int64_t cap);
+
+/* ---- host-buffer entry points: one per reference method ------------------------------- */
+
+/* viterbi(y, lA::StateMatrix, mu, sigma) -> (x::Vector{Int16}, ll)      viterbi.jl:44-98 */
+int hmmsort_viterbi(const double *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
+                    int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
+                    int16_t *x_out, double *ll_out);
+
+/* forward(V, lA::StateMatrix, mu, sigma) -> alpha (S x T)            baumwelch.jl:25-51 */
+int hmmsort_forward(const double *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
+                    int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
+                    double *alpha_out);
+
+/* backward(V, lA::StateMatrix, mu, sigma) -> beta (S x T)            baumwelch.jl:73-98 */
+int hmmsort_backward(const double *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
+                     int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
+                     double *beta_out);
+
+/* update(alpha, beta, lA, mu, sigma, x) -> (StateMatrix, mu, sigma)  baumwelch.jl:205-309
+ * mu_inout (K x N) is zeroed and rewritten in place as the reference does (:268).
+ * lp_out receives xb[2:end] (:264-265): n_lp_out = (#transitions with src == 1) - 1 values
+ * (== N without overlaps); pp_out receives gammaf[:,1] (S values).  The new StateMatrix is
+ * rebuilt by the caller from lp_out (hmmsort_build_transitions or the reference constructor). */
+int hmmsort_update(const double *alpha, const double *beta, const double *x, int64_t T,
+                   const int16_t *states, int64_t N, int64_t K, int64_t S, const hmm_trans *tr,
+                   int64_t R, double *mu_inout, double sigma, double *sigma_out, double *lp_out,
+                   int64_t lp_cap, int64_t *n_lp_out, double *pp_out);
+
+/* train_model(X, state_matrix, mu0, sigma0) = forward -> backward -> update
+ *                                                                    baumwelch.jl:362-370
+ * Same outputs as hmmsort_update; alpha/beta are never materialised by the ring engine. */
+int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
+                    int64_t S, const hmm_trans *tr, int64_t R, double *mu_inout, double sigma,
+                    double *sigma_out, double *lp_out, int64_t lp_cap, int64_t *n_lp_out,
+                    double *pp_out);
+
+/* reconstruct_signal(x, lA, mu, sigma) -> Y2 (sigma is ignored)    reconstruction.jl:1-10 */
+int hmmsort_reconstruct(const int16_t *x, int64_t T, const int16_t *states, int64_t N,
+                        int64_t S, const double *mu, int64_t K, double *y_out);
+
+/* unroll_mlseq(mlseq, state_matrix) -> N x T Int16                   extraction.jl:4-13 */
+int hmmsort_unroll_mlseq(const int16_t *mlseq, int64_t T, const int16_t *states, int64_t N,
+                         int64_t S, int16_t *out);
+
+/* ---- device-resident plan API --------------------------------------------------------- */
+/* Used by bench.py and by multi-GPU hosts: the signal stays in HBM, the caller owns device
+ * buffers (plain device pointers) and the HIP stream (passed as void* == hipStream_t; NULL =
+ * the null stream).  No call below synchronises the stream unless noted. */
+
+typedef struct hmmsort_plan hmmsort_plan;
+
+/* Analyse the model, pick the engine and allocate the device workspace for signals of length T
+ * (one recording channel).  Synchronous. */
+int hmmsort_plan_create(hmmsort_plan **plan_out, int64_t T, const int16_t *states, int64_t N,
+                        int64_t K, int64_t S, const hmm_trans *tr, int64_t R, const double *mu,
+                        double sigma);
+/* Replace transitions / mu / sigma (same N, K, S, R) -- e.g. between EM iterations. */
+int hmmsort_plan_set_model(hmmsort_plan *plan, const hmm_trans *tr, int64_t R, const double *mu,
+                           double sigma);
+int hmmsort_plan_destroy(hmmsort_plan *plan);
+/* engine actually used (HMMSORT_ENGINE_STRICT or HMMSORT_ENGINE_RING), geometry, bytes */
+int hmmsort_plan_info(const hmmsort_plan *plan, int64_t *engine, int64_t *block, int64_t *halo,
+                      int64_t *nchains, int64_t *workspace_bytes);
+
+/* Viterbi decode of d_y[0..T) into d_x[0..T) (device Int16).  d_ll: one device double. */
+int hmmsort_plan_viterbi(hmmsort_plan *plan, const double *d_y, int16_t *d_x, double *d_ll,
+                         void *stream);
+/* E-step: forward-backward + sufficient statistics.  d_stats receives
+ * hmmsort_plan_stats_len() doubles (layout: hmmsort_plan_stats_layout below); the vector is a
+ * plain sum over time, so shards of one recording / pooled channels combine by a SUM
+ * all-reduce (RCCL) before the M-step.  `first`/`last` tell whether this shard starts at the
+ * true beginning / ends at the true end of the recording (both 1 for a whole recording). */
+int hmmsort_plan_estep(hmmsort_plan *plan, const double *d_y, double *d_stats, void *stream);
+int64_t hmmsort_plan_stats_len(const hmmsort_plan *plan);
+/* M-step finish from (all-reduced) statistics, on device: d_out receives
+ * [mu (K*N) | sigma (1) | lp_new (N) | pp (S)] = K*N + 1 + N + S doubles. */
+int hmmsort_plan_mstep(hmmsort_plan *plan, const double *d_stats, double *d_out, void *stream);
+/* diagnostics of the last ring-engine call on this plan (synchronises the stream):
+ * diag[0] = number of chain boundaries whose warm-up check failed (Viterbi),
+ * diag[1] = number of backtrace stitch repairs, diag[2] = halo escalations,
+ * diag[3] = forward-backward boundary failures. */
+int hmmsort_plan_diagnostics(hmmsort_plan *plan, void *stream, int64_t diag[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMMSORT_H */

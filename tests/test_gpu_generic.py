@@ -1,0 +1,159 @@
+"""GPU parity of the generic (reference-order) engine against the CPU oracle, through the C ABI.
+
+Bars: Viterbi path and ll BIT-EXACT (integer/index work and a + - * / > only loop);
+alpha/beta/mu/sigma/lp within 1e-9 relative (north_star asks 1e-6; exp/log1p differ between
+glibc and ROCm's device library by <= 1 ulp per call).  Covers overlap models,
+the chunked decode of fit.jl:11-42 (N3) and edge cases."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import to_oracle_sm, two_templates
+
+pytestmark = pytest.mark.gpu
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.fixture(autouse=True)
+def strict_engine(H):
+    H.set_option("engine", H.ENGINE_STRICT)
+    yield
+    H.set_option("engine", H.ENGINE_AUTO)
+
+
+def _sm_from_gold(H, g):
+    tr = np.zeros(len(g["src"]), dtype=H._lib.TRANS_DTYPE)
+    tr["src"], tr["dst"], tr["lp"] = g["src"], g["dst"], g["val"]
+    S = g["states"].shape[1]
+    return H.StateMatrix(np.asfortranarray(g["states"]), tr, np.zeros(S), int(g["K"]),
+                         int(g["N"]), S, bool(g["ov"]))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_golden_fixture(H, path):
+    g = np.load(path)
+    sm = _sm_from_gold(H, g)
+    temps, y = np.asfortranarray(g["temps"]), g["y"]
+    x, ll = H.viterbi(y, sm, temps, 0.3)
+    assert np.array_equal(x, g["x"])
+    assert ll == float(g["ll"])                       # bit-exact, incl. the summation order
+    a = H.forward(y, sm, temps, 0.3)[:, g["ab_cols"]]
+    b = H.backward(y, sm, temps, 0.3)[:, g["ab_cols"]]
+    assert np.allclose(a, g["alpha"], rtol=1e-9, atol=0)
+    assert np.allclose(b, g["beta"], rtol=1e-9, atol=1e-9)
+    mu = np.asfortranarray(temps * 0.85)
+    mu[0, :] = 0
+    sig, smi = 0.4, sm
+    for step in (1, 2, 3):
+        smi, mu, sig = H.train_step(y, smi, mu, sig)
+        if step in (1, 3):
+            assert np.allclose(mu, g["em%d_mu" % step], rtol=1e-9, atol=1e-12)
+            assert np.isclose(sig, float(g["em%d_sigma" % step]), rtol=1e-9)
+            lp = smi.transitions["lp"]
+            # the rebuilt StateMatrix carries the new lp (baumwelch.jl:265)
+            ref = H.StateMatrix.from_states(sm.states, np.zeros(1), sm.K, g["em%d_lp" % step],
+                                            sm.resolve_overlaps)
+            assert np.allclose(lp, ref.transitions["lp"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("N,K,ov,T,seed", [(2, 60, True, 5000, 1), (3, 40, False, 20000, 2),
+                                           (4, 60, False, 50000, 3), (1, 30, False, 4000, 4),
+                                           (3, 6, True, 3000, 5)])
+def test_viterbi_bit_exact(O, H, N, K, ov, T, seed):
+    rng = np.random.default_rng(seed)
+    amps = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)][:N]
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, *a) for a in amps], 1))
+    pp = rng.uniform(1e-3, 4e-3, N)
+    y = H.create_signal(T, 0.3, pp, temps, seed=seed)
+    sm = H.StateMatrix.create(N, K, np.log(pp), ov)
+    x, ll = H.viterbi(y, sm, temps, 0.3)
+    xo, llo = O.viterbi(y, to_oracle_sm(O, sm), temps, 0.3)
+    assert np.array_equal(x, xo)
+    assert ll == llo
+    assert len(np.unique(x)) > 10  # the decode is not trivially silent
+    # reconstruct_signal + unroll_mlseq: exact
+    assert np.array_equal(H.reconstruct_signal(x, sm, temps, 0.3),
+                          O.reconstruct_signal(xo, to_oracle_sm(O, sm), temps))
+    assert np.array_equal(H.unroll_mlseq(x, sm), O.unroll_mlseq(xo, to_oracle_sm(O, sm)))
+
+
+def test_viterbi_quirks_and_edges(O, H):
+    temps = two_templates(H, 12)
+    sm = H.StateMatrix.create(2, 12, np.log([0.01, 0.02]), False)
+    osm = to_oracle_sm(O, sm)
+    # nonzero mu row 1 (the API allows it; the silent mean is sum_l mu[1,l])
+    mu = temps.copy()
+    mu[0, :] = [0.05, -0.02]
+    y = H.create_signal(700, 0.3, [0.01, 0.02], temps, seed=9)
+    for yy in (y, y[:1], y[:2], np.zeros(300), np.full(50, 7.5)):
+        x, ll = H.viterbi(yy, sm, mu, 0.25)
+        xo, llo = O.viterbi(yy, osm, mu, 0.25)
+        assert np.array_equal(x, xo) and ll == llo
+    # identical templates + equal probabilities: exact ties, lowest source wins (viterbi.jl:80)
+    mu2 = np.asfortranarray(np.stack([temps[:, 0], temps[:, 0]], 1))
+    sm2 = H.StateMatrix.create(2, 12, np.log([0.01, 0.01]), False)
+    x, ll = H.viterbi(y, sm2, mu2, 0.3)
+    xo, llo = O.viterbi(y, to_oracle_sm(O, sm2), mu2, 0.3)
+    assert np.array_equal(x, xo) and ll == llo
+    # empty signal: the reference throws BoundsError at y[1]
+    with pytest.raises(H.HmmsortError):
+        H.viterbi(np.zeros(0), sm, mu, 0.3)
+    with pytest.raises(H.HmmsortError):
+        H.viterbi(y, sm, mu, -1.0)
+    assert len(H.reconstruct_signal(np.zeros(0, np.int16), sm, mu, 0.3)) == 0
+    with pytest.raises(H.HmmsortError):
+        H.reconstruct_signal(np.array([0, 1], np.int16), sm, mu, 0.3)  # BoundsError in Julia
+
+
+def test_forward_backward_update(O, H):
+    temps = two_templates(H, 25)
+    pp = [0.008, 0.005]
+    for ov in (False, True):
+        sm = H.StateMatrix.create(2, 25, np.log(pp), ov)
+        osm = to_oracle_sm(O, sm)
+        y = H.create_signal(1200, 0.3, pp, temps, seed=21)
+        mu = np.asfortranarray(temps * 0.9)
+        mu[0, :] = 0
+        a, b = H.forward(y, sm, mu, 0.35), H.backward(y, sm, mu, 0.35)
+        ao, bo = O.forward(y, osm, mu, 0.35), O.backward(y, osm, mu, 0.35)
+        assert np.allclose(a, ao, rtol=1e-10, atol=0) and np.allclose(b, bo, rtol=1e-10, atol=1e-9)
+        # update() from the oracle's alpha/beta: isolates the M-step kernels
+        mu_g = mu.copy(order="F")
+        sm_n, mu_n, sig_n = H.update(ao, bo, sm, mu_g, 0.35, y)
+        osm_n, omu, osig, olp, opp = O.update(ao, bo, osm, mu, 0.35, y)
+        assert np.allclose(mu_n, omu, rtol=1e-9, atol=1e-12) and np.isclose(sig_n, osig, rtol=1e-10)
+        assert np.array_equal(mu_g, mu_n)               # in place, baumwelch.jl:268
+        assert len(sm_n.transitions) == len(osm_n.src)
+        assert np.allclose(sm_n.transitions["lp"], osm_n.val, rtol=1e-9)
+        assert np.allclose(sm_n.pi, opp, rtol=1e-9, atol=1e-9)
+
+
+def test_chunked_fit_matches_reference_rule(O, H):
+    # fit.jl:11-42 stitch semantics
+    temps = two_templates(H, 30)
+    pp = [0.004, 0.003]
+    sm = H.StateMatrix.create(2, 30, np.log(pp), False)
+    y = H.create_signal(6000, 0.3, pp, temps, seed=33)
+    model = H.fit(H.HMMSpikeTemplateModel(sm, temps, 0.3), y, chunksize=1000)
+    rc, ml, ll = O.fit_chunked(y, to_oracle_sm(O, sm), temps, 0.3, 1000)
+    assert rc == 0 and np.array_equal(model.ml_seq, ml) and model.ll == ll
+    assert np.array_equal(H.predict(model), O.reconstruct_signal(ml, to_oracle_sm(O, sm), temps))
+
+
+def test_train_model_driver(O, H):
+    # baumwelch.jl:324-354 loop semantics: callback(mu) before every step, nsteps + nsteps//2 steps
+    temps = two_templates(H, 20)
+    pp = [0.01, 0.006]
+    y = H.create_signal(3000, 0.3, pp, temps, seed=5)
+    sm = H.StateMatrix.create(2, 20, np.log(pp), False)
+    mu0 = np.asfortranarray(temps * 0.8)
+    mu0[0, :] = 0
+    seen = []
+    smn, mu, sig = H.train_model(y, sm, mu0.copy(order="F"), 0.5, 2, lambda m: seen.append(m.copy()))
+    assert len(seen) == 2 and np.array_equal(seen[0], mu0)
+    osm, omu, osig = to_oracle_sm(O, sm), mu0.copy(order="F"), 0.5
+    for _ in range(3):
+        osm, omu, osig, _, _ = O.train_step(y, osm, omu, osig)
+    assert np.allclose(mu, omu, rtol=1e-8, atol=1e-11) and np.isclose(sig, osig, rtol=1e-9)
