@@ -420,8 +420,10 @@ int hmm_oracle_fit_chunked(const double *X, int64_t n, int64_t chunksize, const 
         int rc = hmm_oracle_viterbi(X + (i - 1), k, states1, N, K, S, src, dst, val, R, mu, sigma,
                                     x, &_ll, 1, NULL);
         if (rc) { free(x); return rc; }
-        if (i > 1)
+        if (i > 1) {
             while (l <= k && x[l - 1] > 1) l++;
+            if (l > k) { free(x); *ll_out = ll; return -3; } /* reference: BoundsError at x[l] */
+        }
         if (j < n)
             while (k >= 1 && x[k - 1] > 1) { j--; k--; }
         for (int64_t u = l; u <= k; u++) ml_seq[(i + u - 1) - 1] = x[u - 1];

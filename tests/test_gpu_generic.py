@@ -136,10 +136,18 @@ def test_chunked_fit_matches_reference_rule(O, H):
     pp = [0.004, 0.003]
     sm = H.StateMatrix.create(2, 30, np.log(pp), False)
     y = H.create_signal(6000, 0.3, pp, temps, seed=33)
-    model = H.fit(H.HMMSpikeTemplateModel(sm, temps, 0.3), y, chunksize=1000)
-    rc, ml, ll = O.fit_chunked(y, to_oracle_sm(O, sm), temps, 0.3, 1000)
-    assert rc == 0 and np.array_equal(model.ml_seq, ml) and model.ll == ll
-    assert np.array_equal(H.predict(model), O.reconstruct_signal(ml, to_oracle_sm(O, sm), temps))
+    for cs in (1500, 2500):
+        model = H.fit(H.HMMSpikeTemplateModel(sm, temps, 0.3), y, chunksize=cs)
+        rc, ml, ll = O.fit_chunked(y, to_oracle_sm(O, sm), temps, 0.3, cs)
+        assert rc == 0 and np.array_equal(model.ml_seq, ml) and model.ll == ll
+        assert np.array_equal(H.predict(model),
+                              O.reconstruct_signal(ml, to_oracle_sm(O, sm), temps))
+    # a chunk that decodes without any silent sample: the reference dies with a BoundsError at
+    # x[l] (fit.jl:26); the mirror raises IndexError and the oracle reports -3 at the same place
+    rc, _, _ = O.fit_chunked(y, to_oracle_sm(O, sm), temps, 0.3, 1000)
+    assert rc == -3
+    with pytest.raises(IndexError):
+        H.fit(H.HMMSpikeTemplateModel(sm, temps, 0.3), y, chunksize=1000)
 
 
 def test_train_model_driver(O, H):
