@@ -1,0 +1,139 @@
+// Shared declarations of the time-parallel ring engine (ring_engine.hip, ring_viterbi.hip,
+// ring_estep.hip).  See DESIGN.md "Ring engine" for the derivation; short version:
+//
+// Without overlaps the model (reference types.jl:94-113) is N deterministic rings of L = K-1
+// states through one silent state.  Only N+1 states have more than one predecessor: the silent
+// state and each ring's first state ("junctions").  A ring is a pure delay line: the value that
+// enters ring a at time t' leaves it at t'+L-1 having collected the ring score
+//     Rfull_a(t') = sum_{k=1..L} q(y[t'+k-1]; mean(a,k)) + sum_{k=1..L-1} lp((a,k)->(a,k+1)),
+// which does not depend on the recursion and is computed for all t' in parallel ("pre-pass").
+// The serial part of Viterbi / forward / backward then touches N+1 numbers per sample.
+//
+// Time parallelism: the recording is cut into chains of B samples; chain c is advanced by ONE
+// LANE (64 chains per wavefront, no cross-lane traffic) from a warm-up start H samples early.
+// All per-sample arrays are stored TRANSPOSED, element (row = t mod B, column = t div B), so that
+// the 64 lanes of a wavefront (64 consecutive chains, same step) touch 512 contiguous bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hmmsort_internal.h"
+
+namespace hmmsort {
+
+constexpr int kRingMaxN = 16;
+constexpr int kRingMinL = 16;
+
+struct RingGeom {
+    int64_t T;     // samples
+    int N, L;      // rings, ring length (K-1)
+    int B, H;      // chain length, warm-up length (multiples of 64, H <= B)
+    int nch;       // chains = ceil(T/B); every chain has >= L samples
+    int ncol;      // columns of the transposed arrays (nch rounded up to 64)
+    int Lc;        // halo-tail length kept for the boundary check (<= H)
+    int bits, epw, W;  // psi packing: bits per entry, entries per 32-bit word, words per sample
+};
+
+// junction constants, passed to kernels by value (kernarg segment -> scalar loads)
+template <int N>
+struct JParams {
+    double c00;         // silent -> silent
+    double c0[N];       // silent -> (a,1)
+    double cend[N];     // (a,L)  -> silent
+    double cx[N * N];   // (a,L)  -> (b,1)   [a*N+b]
+    double mean0;       // mean of the silent state
+    double den;         // 2*sigma^2
+    double A;           // -log2pi - log(sigma): the per-sample emission constant
+};
+
+// same constants in the linear domain for the log-sum-exp junction updates
+template <int N>
+struct EParams {
+    double p00;
+    double p0[N];
+    double pend[N];
+    double px[N * N];
+    double mean0;
+    double den;
+};
+
+struct RingDev {
+    RingGeom g{};
+    int64_t S = 0, K = 0;
+    double sigma = 0, lsig = 0, A = 0, den = 0;
+    RingModel ring;               // host copy of the transition constants
+    std::vector<double> mean;     // host copy of per-state means
+    // device model tables
+    double *d_mean = nullptr;     // S
+    double *d_cint = nullptr;     // N*(L+1): Cint[a][kk] = sum_{k=1}^{kk-1} lp((a,k)->(a,k+1))
+    double *d_ctab = nullptr;     // 1 + N + N + N*N + N*L: c00 | c0 | cend | cx | cint
+    int16_t *d_states = nullptr;  // N x S (for the M-step pack)
+    // device work arrays (allocated once per plan)
+    double *yT = nullptr;         // B x ncol
+    double *Rf = nullptr;         // N planes of B x ncol
+    double *P = nullptr;          // N planes of (H+B) x ncol   (Viterbi delay line / fwd lp)
+    double *Q = nullptr;          // N planes of (L+B+H) x ncol (bwd ly)                 [E-step]
+    double *A0 = nullptr;         // (1+B) x ncol fwd silent (row 0 = value before the chain)
+    double *B0 = nullptr;         // B x ncol bwd silent
+    uint32_t *psi = nullptr;      // W planes of B x ncol
+    uint32_t *psiH = nullptr;     // W planes of Lc x ncol
+    double *D0end = nullptr;      // ncol
+    int32_t *bstate = nullptr;    // ncol
+    int32_t *redo = nullptr;      // list of chains to re-walk (capacity ncol)
+    int16_t *xT = nullptr;        // B x ncol
+    int32_t *final_state = nullptr;
+    double *part = nullptr;       // reduction partials
+    double *Zc = nullptr;         // ncol per-chain normalisers
+    double *stats_part = nullptr; // E-step partial sums
+    int64_t *diag = nullptr;      // 8 device counters
+    int64_t bytes = 0;
+    int nparts = 0;
+};
+
+template <typename F>
+inline int dispatch_N(int N, F &&f)
+{
+    switch (N) {
+    case 1: return f(std::integral_constant<int, 1>());
+    case 2: return f(std::integral_constant<int, 2>());
+    case 3: return f(std::integral_constant<int, 3>());
+    case 4: return f(std::integral_constant<int, 4>());
+    case 5: return f(std::integral_constant<int, 5>());
+    case 6: return f(std::integral_constant<int, 6>());
+    case 7: return f(std::integral_constant<int, 7>());
+    case 8: return f(std::integral_constant<int, 8>());
+    case 9: return f(std::integral_constant<int, 9>());
+    case 10: return f(std::integral_constant<int, 10>());
+    case 11: return f(std::integral_constant<int, 11>());
+    case 12: return f(std::integral_constant<int, 12>());
+    case 13: return f(std::integral_constant<int, 13>());
+    case 14: return f(std::integral_constant<int, 14>());
+    case 15: return f(std::integral_constant<int, 15>());
+    case 16: return f(std::integral_constant<int, 16>());
+    }
+    set_error("ring engine: N = %d outside 1..%d", N, kRingMaxN);
+    return HMMSORT_EUNSUP;
+}
+
+// psi packing as compile-time functions of N (must agree with RingGeom.bits/epw/W)
+constexpr int psi_bits_c(int N) { int b = 1; while ((1 << b) < N + 1) b++; return b; }
+constexpr int psi_epw_c(int N) { return 32 / psi_bits_c(N); }
+constexpr int psi_words_c(int N) { return (N + 1 + psi_epw_c(N) - 1) / psi_epw_c(N); }
+
+// steps per software-pipelined batch of the chain kernels
+template <int N> constexpr int chain_unroll() { return N <= 4 ? 4 : (N <= 8 ? 2 : 1); }
+// rows per thread of the pre-pass
+template <int N> constexpr int prepass_rows() { return N <= 4 ? 16 : (N <= 8 ? 8 : 4); }
+
+// ring_viterbi.hip
+int ring_viterbi_launch(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st);
+// ring_estep.hip
+int ring_estep_launch(RingDev *r, const double *d_y, double *d_stats, hipStream_t st);
+int ring_mstep_launch(RingDev *r, const double *d_stats, double *d_out, hipStream_t st);
+// shared launch helpers (ring_engine.hip)
+int ring_launch_transpose_in(RingDev *r, const double *d_y, hipStream_t st);
+int ring_launch_prepass(RingDev *r, hipStream_t st);
+int ring_launch_virtual(RingDev *r, const double *d_y, double *dst_planes, int64_t plane_stride,
+                        hipStream_t st);
+
+}  // namespace hmmsort

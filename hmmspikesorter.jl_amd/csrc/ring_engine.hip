@@ -1,16 +1,334 @@
-// placeholder, replaced below by the real ring engine
-#include "hmmsort_internal.h"
+// Ring engine, part 1: geometry, workspace, transposes, the parallel pre-pass (ring scores).
+// Design notes: ring_common.h / DESIGN.md.
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+
+#include "ring_common.h"
+
 namespace hmmsort {
-struct RingDev { int dummy; };
-bool ring_supported(const HostModel &, int64_t, std::string *why) { if (why) *why = "not built yet"; return false; }
-int ring_create(RingDev **, const HostModel &, int64_t) { return HMMSORT_EUNSUP; }
-int ring_set_model(RingDev *, const HostModel &) { return HMMSORT_EUNSUP; }
-void ring_destroy(RingDev *) {}
-int64_t ring_workspace_bytes(const RingDev *) { return 0; }
-void ring_geometry(const RingDev *, int64_t *, int64_t *, int64_t *) {}
-int ring_viterbi(RingDev *, const double *, int16_t *, double *, hipStream_t) { return HMMSORT_EUNSUP; }
-int ring_estep(RingDev *, const double *, double *, hipStream_t) { return HMMSORT_EUNSUP; }
-int ring_mstep(RingDev *, const double *, double *, hipStream_t) { return HMMSORT_EUNSUP; }
-int64_t ring_stats_len(const RingDev *) { return 0; }
-int ring_diagnostics(RingDev *, hipStream_t, int64_t *) { return HMMSORT_OK; }
+
+// ------------------------------------------------------------------------------------------
+// geometry
+// ------------------------------------------------------------------------------------------
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+bool ring_supported(const HostModel &m, int64_t T, std::string *why)
+{
+    auto no = [&](const char *w) { if (why) *why = w; return false; };
+    if (!m.ring.valid) return no("transition list is not the no-overlap ring pattern");
+    if (m.ring.N > kRingMaxN) return no("more than 16 rings");
+    if (m.ring.L < kRingMinL) return no("rings shorter than 16 states");
+    if (T < 4 * (int64_t)m.ring.L || T < 512) return no("signal shorter than 4 ring lengths / 512 samples");
+    return true;
 }
+
+static int make_geometry(RingGeom &g, int64_t T, int N, int L)
+{
+    const Options &o = options();
+    g.T = T; g.N = N; g.L = L;
+    // warm-up: >= 4 ring lengths and >= 256 samples (see DESIGN.md "halo")
+    int64_t H = o.halo > 0 ? o.halo : std::max<int64_t>(256, 4 * (int64_t)L);
+    H = round_up(std::max<int64_t>(H, L + 1), 64);
+    // chain length: enough chains to fill 1024 SIMDs x 64 lanes, but never shorter than the halo
+    int64_t B = o.block > 0 ? o.block : std::max<int64_t>(H, (T + 65535) / 65536);
+    B = round_up(std::max<int64_t>(B, std::max<int64_t>(H, L)), 64);
+    if (B > T) B = round_up(T, 64);
+    if (H > B) H = B;
+    // every chain must own >= L samples (the per-chain normaliser needs a full ring window)
+    for (;;) {
+        int64_t nch = (T + B - 1) / B;
+        int64_t nlast = T - (nch - 1) * B;
+        if (nch == 1 || nlast >= L) break;
+        B += 64;
+    }
+    HS_CHECK(B + H + L < (1 << 30), HMMSORT_EINVAL, "ring engine: block too long");
+    g.B = (int)B; g.H = (int)H;
+    g.nch = (int)((T + B - 1) / B);
+    g.ncol = (int)round_up(g.nch, 64);
+    g.Lc = (int)std::min<int64_t>(H, 2 * (int64_t)L);
+    int bits = 1;
+    while ((1 << bits) < N + 1) bits++;
+    g.bits = bits; g.epw = 32 / bits; g.W = (N + 1 + g.epw - 1) / g.epw;
+    return HMMSORT_OK;
+}
+
+template <typename Tv>
+static int dmalloc(Tv **p, int64_t n, int64_t *bytes)
+{
+    if (hipMalloc((void **)p, (size_t)std::max<int64_t>(n, 1) * sizeof(Tv)) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("ring engine: hipMalloc of %.2f GB failed", n * sizeof(Tv) / 1e9);
+        *p = nullptr;
+        return HMMSORT_ENOMEM;
+    }
+    *bytes += n * (int64_t)sizeof(Tv);
+    return HMMSORT_OK;
+}
+
+int ring_set_model(RingDev *r, const HostModel &m)
+{
+    HS_CHECK(m.ring.valid && m.ring.N == r->g.N && m.ring.L == r->g.L && m.S == r->S,
+             HMMSORT_EINVAL, "ring set_model: model shape changed");
+    r->ring = m.ring;
+    r->mean = m.mean;
+    r->sigma = m.sigma;
+    r->lsig = std::log(m.sigma);
+    r->A = -kLog2Pi - r->lsig;
+    r->den = 2.0 * (m.sigma * m.sigma);
+    const int N = r->g.N, L = r->g.L;
+    HS_HIP(hipMemcpy(r->d_mean, m.mean.data(), m.S * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> cint((size_t)N * (L + 1), 0.0);
+    for (int a = 0; a < N; a++) {
+        double acc = 0.0;
+        cint[(size_t)a * (L + 1) + 0] = 0.0;
+        cint[(size_t)a * (L + 1) + 1] = 0.0;
+        for (int kk = 2; kk <= L; kk++) {
+            acc += m.ring.cint[(size_t)a * L + (kk - 1)];  // lp((a,kk-1)->(a,kk))
+            cint[(size_t)a * (L + 1) + kk] = acc;
+        }
+    }
+    HS_HIP(hipMemcpy(r->d_cint, cint.data(), cint.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> ctab;
+    ctab.push_back(m.ring.c00);
+    ctab.insert(ctab.end(), m.ring.c0.begin(), m.ring.c0.end());
+    ctab.insert(ctab.end(), m.ring.cend.begin(), m.ring.cend.end());
+    ctab.insert(ctab.end(), m.ring.cx.begin(), m.ring.cx.end());
+    ctab.insert(ctab.end(), m.ring.cint.begin(), m.ring.cint.end());
+    HS_HIP(hipMemcpy(r->d_ctab, ctab.data(), ctab.size() * sizeof(double), hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(r->d_states, m.states.data(), m.states.size() * sizeof(int16_t),
+                     hipMemcpyHostToDevice));
+    return HMMSORT_OK;
+}
+
+int ring_create(RingDev **out, const HostModel &m, int64_t T)
+{
+    std::string why;
+    HS_CHECK(ring_supported(m, T, &why), HMMSORT_EUNSUP, "ring engine: %s", why.c_str());
+    RingDev *r = new RingDev();
+    int rc = make_geometry(r->g, T, m.ring.N, m.ring.L);
+    if (rc) { delete r; return rc; }
+    r->S = m.S; r->K = m.K;
+    const RingGeom &g = r->g;
+    const int64_t BC = (int64_t)g.B * g.ncol, N = g.N, L = g.L;
+    r->nparts = 1024;
+    bool ok = true;
+    auto A = [&](auto **p, int64_t n) { if (ok && dmalloc(p, n, &r->bytes)) ok = false; };
+    A(&r->d_mean, m.S);
+    A(&r->d_cint, N * (L + 1));
+    A(&r->d_ctab, 1 + 2 * N + N * N + N * L);
+    A(&r->d_states, N * m.S);
+    A(&r->yT, BC);
+    A(&r->Rf, N * BC);
+    A(&r->P, N * (int64_t)(g.H + g.B) * g.ncol);
+    A(&r->Q, N * (int64_t)(g.L + g.B + g.H) * g.ncol);
+    A(&r->A0, (int64_t)(1 + g.B) * g.ncol);
+    A(&r->B0, BC);
+    A(&r->psi, (int64_t)g.W * BC);
+    A(&r->psiH, (int64_t)g.W * g.Lc * g.ncol);
+    A(&r->D0end, g.ncol);
+    A(&r->bstate, g.ncol);
+    A(&r->redo, g.ncol + 8);
+    A(&r->xT, BC);
+    A(&r->final_state, 8);
+    A(&r->part, 4 * r->nparts);
+    A(&r->Zc, g.ncol);
+    A(&r->stats_part, (int64_t)r->nparts * (3 * N * L + 8 + 2 * N));
+    A(&r->diag, 8);
+    if (!ok) { ring_destroy(r); return HMMSORT_ENOMEM; }
+    if (hipMemset(r->diag, 0, 8 * sizeof(int64_t)) != hipSuccess) { ring_destroy(r); return HMMSORT_EHIP; }
+    rc = ring_set_model(r, m);
+    if (rc) { ring_destroy(r); return rc; }
+    *out = r;
+    return HMMSORT_OK;
+}
+
+void ring_destroy(RingDev *r)
+{
+    if (!r) return;
+    void *ptrs[] = {r->d_mean, r->d_cint, r->d_ctab, r->d_states, r->yT, r->Rf, r->P, r->Q, r->A0,
+                    r->B0, r->psi, r->psiH, r->D0end, r->bstate, r->redo, r->xT, r->final_state,
+                    r->part, r->Zc, r->stats_part, r->diag};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete r;
+}
+
+int64_t ring_workspace_bytes(const RingDev *r) { return r->bytes; }
+void ring_geometry(const RingDev *r, int64_t *block, int64_t *halo, int64_t *nchains)
+{
+    if (block) *block = r->g.B;
+    if (halo) *halo = r->g.H;
+    if (nchains) *nchains = r->g.nch;
+}
+
+int ring_diagnostics(RingDev *r, hipStream_t st, int64_t diag[8])
+{
+    HS_HIP(hipStreamSynchronize(st));
+    HS_HIP(hipMemcpy(diag, r->diag, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return HMMSORT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// transposes:  y[c*B + s]  <->  yT[s*ncol + c]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose_in(const double *__restrict__ y, int64_t T,
+                                                      int B, int ncol, double *__restrict__ yT)
+{
+    __shared__ double tile[64][65];
+    const int s0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int cl = ty + 4 * i;
+        const int64_t t = (int64_t)(c0 + cl) * B + s0 + tx;
+        tile[cl][tx] = (t < T) ? y[t] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int sl = ty + 4 * i;
+        yT[(int64_t)(s0 + sl) * ncol + c0 + tx] = tile[tx][sl];
+    }
+}
+
+int ring_launch_transpose_in(RingDev *r, const double *d_y, hipStream_t st)
+{
+    const RingGeom &g = r->g;
+    hipLaunchKernelGGL(k_transpose_in, dim3(g.B / 64, g.ncol / 64), dim3(256), 0, st, d_y, g.T, g.B,
+                       g.ncol, r->yT);
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// pre-pass: ring scores for every onset time t' in [0, T)
+//   Rf[a][t'] = -(1/den) * sum_{k=1..kmax} (y[t'+k-1] - mean(a,k))^2 + Cint[a][kmax],
+//   kmax = min(L, T - t')   (rings that run off the end of the data are truncated: the
+//   reference's terminal conditions, viterbi.jl:90 / baumwelch.jl:80).
+// The per-sample constant A = -log2pi - log(sigma) is left out everywhere (it shifts every state
+// of a time step equally and cancels from every decision and posterior); ll adds it back.
+// One thread = one chain column x RS consecutive rows; a y sample is loaded once and feeds the
+// RS overlapping windows from registers.  Means are wave-uniform (scalar loads).
+// ------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void k_prepass(RingGeom g, const double *__restrict__ yT,
+                                                 const double *__restrict__ mean,
+                                                 const double *__restrict__ cint, double den,
+                                                 double *__restrict__ Rf)
+{
+    constexpr int RS = prepass_rows<N>();
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int s0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RS;
+    const int L = g.L, B = g.B, ncol = g.ncol;
+    const int64_t T = g.T;
+    const int64_t tbase = (int64_t)c * B + s0;
+    double acc[RS][N];
+#pragma unroll
+    for (int r = 0; r < RS; r++)
+#pragma unroll
+        for (int a = 0; a < N; a++) acc[r][a] = 0.0;
+    const int nj = RS + L - 1;
+    for (int j = 0; j < nj; j++) {
+        const int row = s0 + j;
+        const int64_t t = tbase + j;
+        double v = 0.0;
+        const bool in = (t < T) && (c < g.nch);
+        if (in) v = (row < B) ? yT[(int64_t)row * ncol + c] : yT[(int64_t)(row - B) * ncol + c + 1];
+#pragma unroll
+        for (int r = 0; r < RS; r++) {
+            const int k = j - r + 1;  // ring phase of sample t for the window starting at s0+r
+            if (k >= 1 && k <= L) {   // wave-uniform
+#pragma unroll
+                for (int a = 0; a < N; a++) {
+                    const double d = v - mean[1 + a * L + (k - 1)];
+                    acc[r][a] += in ? d * d : 0.0;
+                }
+            }
+        }
+    }
+    if (c >= g.nch) return;
+#pragma unroll
+    for (int r = 0; r < RS; r++) {
+        const int64_t t0 = tbase + r;
+        if (t0 < T) {
+            const int64_t rem = T - t0;
+            const int kmax = rem < L ? (int)rem : L;
+#pragma unroll
+            for (int a = 0; a < N; a++)
+                Rf[(int64_t)a * B * ncol + (int64_t)(s0 + r) * ncol + c] =
+                    cint[a * (L + 1) + kmax] - acc[r][a] / den;
+        }
+    }
+}
+
+int ring_launch_prepass(RingDev *r, hipStream_t st)
+{
+    const RingGeom &g = r->g;
+    return dispatch_N(g.N, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        constexpr int RS = prepass_rows<N>();
+        hipLaunchKernelGGL((k_prepass<N>), dim3(g.ncol / 64, g.B / (4 * RS)), dim3(256), 0, st, g,
+                           r->yT, r->d_mean, r->d_cint, r->den, r->Rf);
+        HS_HIP(hipGetLastError());
+        return HMMSORT_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// virtual onsets t' = -j, j = 1..L-1: rings already running at the first sample (the
+// reference's first column is "emission only" for every state: viterbi.jl:55-62,
+// baumwelch.jl:36).  Their score covers phases k = 1+j..L on samples 0..L-1-j.  Written into
+// chain 0's (otherwise unused) warm-up rows of the delay-line array: row H-j, column 0; row H-L
+// is the "no such onset" marker -Inf.
+// ------------------------------------------------------------------------------------------
+__global__ void k_virtual(RingGeom g, const double *__restrict__ y, const double *__restrict__ mean,
+                          const double *__restrict__ cint, double den, double *__restrict__ dst,
+                          int64_t plane_stride)
+{
+    const int L = g.L, N = g.N;
+    for (int i = threadIdx.x; i < N * L; i += blockDim.x) {
+        const int a = i / L, j = i % L + 1;  // j = 1..L
+        double v;
+        if (j == L) {
+            v = -INFINITY;
+        } else {
+            double acc = 0.0;
+            for (int k = 1 + j; k <= L; k++) {
+                const double d = y[k - 1 - j] - mean[1 + a * L + (k - 1)];
+                acc += d * d;
+            }
+            v = (cint[a * (L + 1) + L] - cint[a * (L + 1) + (1 + j)]) - acc / den;
+        }
+        dst[(int64_t)a * plane_stride + (int64_t)(g.H - j) * g.ncol + 0] = v;
+    }
+}
+
+int ring_launch_virtual(RingDev *r, const double *d_y, double *dst, int64_t plane_stride,
+                        hipStream_t st)
+{
+    hipLaunchKernelGGL(k_virtual, dim3(1), dim3(256), 0, st, r->g, d_y, r->d_mean, r->d_cint, r->den,
+                       dst, plane_stride);
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+int ring_viterbi(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st)
+{
+    return ring_viterbi_launch(r, d_y, d_x, d_ll, st);
+}
+int ring_estep(RingDev *r, const double *d_y, double *d_stats, hipStream_t st)
+{
+    return ring_estep_launch(r, d_y, d_stats, st);
+}
+int ring_mstep(RingDev *r, const double *d_stats, double *d_out, hipStream_t st)
+{
+    return ring_mstep_launch(r, d_stats, d_out, st);
+}
+int64_t ring_stats_len(const RingDev *r)
+{
+    // per ring state G0,G1,G2 | per ring: xi-sum | gamma0 sums (all t, t<T-1), gamma0*y^2, loglik
+    return 3 * (int64_t)r->g.N * r->g.L + r->g.N + 4;
+}
+
+}  // namespace hmmsort

@@ -1,0 +1,479 @@
+// Ring engine, part 2: time-parallel Viterbi (reference src/viterbi.jl:44-98).
+//
+// Per sample t (0-based) the serial recursion keeps, per chain (= per lane):
+//   D0          = delta_t(silent)
+//   P_a(t')     = delta of ring a's LAST state at time t'+L-1 for the onset at t'
+//               = U_a(t') + Rfull_a(t'),  U_a(t') = best predecessor score of state (a,1) at t'
+// and decides, for the N+1 junction states, the back-pointer psi in {0 = silent, b = ring b's
+// last state}.  Candidates are scanned in source-state order (silent first, then rings
+// ascending) with a strict '>' -- the reference's tie rule (viterbi.jl:74-84).
+// Everything is relative to the frame delta'_t = delta_t - A*(t+1) (A = emission constant).
+//
+// Exactness: inside one chain the arithmetic differs from the reference's only by rounding at
+// the 1e-13 level (ring scores are pre-summed; each chain carries its own small offset instead
+// of the reference's O(T) cumulative sum, whose own rounding unit is larger).  A decoded path can
+// therefore differ from the reference only where two alternatives tie within rounding noise of
+// the reference itself.  hmmsort_set_option("engine", STRICT) gives the op-for-op engine.
+#include <cmath>
+#include <type_traits>
+
+#include "ring_common.h"
+
+namespace hmmsort {
+
+template <int N>
+struct VitIn {
+    double y;
+    double R[N];
+    double X[N];
+};
+
+// One lane = one chain.  grid = ncol/64 blocks of 64 threads.
+template <int N>
+__global__ __launch_bounds__(64) void k_vit_chain(RingGeom g, JParams<N> jp,
+                                                  const double *__restrict__ yT,
+                                                  const double *__restrict__ Rf,
+                                                  double *__restrict__ P,
+                                                  uint32_t *__restrict__ psi,
+                                                  uint32_t *__restrict__ psiH,
+                                                  double *__restrict__ D0end)
+{
+    constexpr int U = chain_unroll<N>();
+    constexpr int BITS = psi_bits_c(N), EPW = psi_epw_c(N), W = psi_words_c(N);
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int B = g.B, H = g.H, L = g.L, ncol = g.ncol, Lc = g.Lc;
+    const bool active = c < g.nch;
+    const int64_t tc = (int64_t)c * B;
+    const int nc = active ? (int)((g.T - tc) < B ? (g.T - tc) : B) : 0;
+    const int s0 = (c == 0) ? 0 : -H;
+    const int64_t planeR = (int64_t)B * ncol, planeP = (int64_t)(H + B) * ncol;
+    const int64_t planePsi = (int64_t)B * ncol, planePsiH = (int64_t)Lc * ncol;
+    const int cin = c > 0 ? c - 1 : 0;
+
+    auto load = [&](VitIn<N>(&d)[U], int sb) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int s = sb + u;
+            const bool live = active && s >= s0 && s < nc;
+            d[u].y = 0.0;
+#pragma unroll
+            for (int a = 0; a < N; a++) { d[u].R[a] = 0.0; d[u].X[a] = -INFINITY; }
+            if (live) {
+                const int64_t off = (s >= 0) ? (int64_t)s * ncol + c : (int64_t)(B + s) * ncol + cin;
+                d[u].y = yT[off];
+#pragma unroll
+                for (int a = 0; a < N; a++) d[u].R[a] = Rf[a * planeR + off];
+                if (s - L >= -H) {
+                    const int64_t offp = (int64_t)(H + s - L) * ncol + c;
+#pragma unroll
+                    for (int a = 0; a < N; a++) d[u].X[a] = P[a * planeP + offp];
+                }
+            }
+        }
+    };
+
+    VitIn<N> cur[U], nxt[U];
+    double D0 = 0.0;
+    const int sfirst = -H;  // wave-uniform loop start (chain 0 idles through the warm-up steps)
+    load(cur, sfirst);
+    for (int sb = sfirst; sb < B; sb += U) {
+        if (sb + U < B) load(nxt, sb + U);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int s = sb + u;
+            const bool live = active && s >= s0 && s < nc;
+            if (live) {
+                double Pn[N];
+                uint32_t pw[W];
+#pragma unroll
+                for (int w = 0; w < W; w++) pw[w] = 0u;
+                if (s == s0) {
+                    // first sample of the chain: chain 0 = the reference's first column
+                    // (viterbi.jl:55-63: emission only, T1[1,1] = 0); others = "silent, rings
+                    // empty" warm-up start
+                    if (c == 0) {
+                        D0 = -jp.A;
+#pragma unroll
+                        for (int a = 0; a < N; a++) Pn[a] = cur[u].R[a];
+                    } else {
+                        D0 = 0.0;
+#pragma unroll
+                        for (int a = 0; a < N; a++) Pn[a] = -INFINITY;
+                    }
+                } else {
+                    double best0 = D0 + jp.c00;
+                    int p0 = 0;
+#pragma unroll
+                    for (int a = 0; a < N; a++) {
+                        const double v = cur[u].X[a] + jp.cend[a];
+                        if (v > best0) { best0 = v; p0 = a + 1; }
+                    }
+                    pw[0] = (uint32_t)p0;
+#pragma unroll
+                    for (int a = 0; a < N; a++) {
+                        double ua = D0 + jp.c0[a];
+                        int pa = 0;
+#pragma unroll
+                        for (int b = 0; b < N; b++) {
+                            if (b == a) continue;
+                            const double v = cur[u].X[b] + jp.cx[b * N + a];
+                            if (v > ua) { ua = v; pa = b + 1; }
+                        }
+                        Pn[a] = ua + cur[u].R[a];
+                        pw[(a + 1) / EPW] |= (uint32_t)pa << (((a + 1) % EPW) * BITS);
+                    }
+                    const double d = cur[u].y - jp.mean0;
+                    D0 = best0 - (d * d) / jp.den;
+                }
+                const int64_t offp = (int64_t)(H + s) * ncol + c;
+#pragma unroll
+                for (int a = 0; a < N; a++) P[a * planeP + offp] = Pn[a];
+                if (s >= 0) {
+                    const int64_t o = (int64_t)s * ncol + c;
+#pragma unroll
+                    for (int w = 0; w < W; w++) psi[w * planePsi + o] = pw[w];
+                } else if (s >= -Lc) {
+                    const int64_t o = (int64_t)(Lc + s) * ncol + c;
+#pragma unroll
+                    for (int w = 0; w < W; w++) psiH[w * planePsiH + o] = pw[w];
+                }
+                if (s == nc - 1) D0end[c] = D0;
+            }
+        }
+        if (sb + U < B) {
+#pragma unroll
+            for (int u = 0; u < U; u++) cur[u] = nxt[u];
+        }
+    }
+}
+
+// Final state = argmax over all S states at the last sample, first maximum in state order
+// (viterbi.jl:90).  delta(a,k) at T-1 is P_a(T-k) (truncated ring score).  One wave.
+__global__ __launch_bounds__(64) void k_vit_tail(RingGeom g, const double *__restrict__ P,
+                                                 const double *__restrict__ D0end,
+                                                 int32_t *__restrict__ final_state)
+{
+    const int lane = threadIdx.x;
+    const int c = g.nch - 1;
+    const int64_t tc = (int64_t)c * g.B;
+    const int64_t planeP = (int64_t)(g.H + g.B) * g.ncol;
+    const int S = 1 + g.N * g.L;
+    double best = -INFINITY;
+    int bi = S;  // sentinel
+    for (int j = lane; j < S; j += 64) {
+        double v;
+        if (j == 0) {
+            v = D0end[c];
+        } else {
+            const int a = (j - 1) / g.L, k = (j - 1) % g.L + 1;
+            const int64_t s = (g.T - k) - tc;  // onset time T-k relative to the last chain
+            v = P[a * planeP + (int64_t)(g.H + s) * g.ncol + c];
+        }
+        if (v > best) { best = v; bi = j; }  // ascending j per lane: keeps the first maximum
+    }
+    // wave argmax, lowest index on ties
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) final_state[0] = (bi >= S) ? 0 : bi;
+}
+
+__device__ __forceinline__ int psi_get(const RingGeom &g, const uint32_t *__restrict__ psi,
+                                       int64_t plane, int64_t off, int e)
+{
+    const uint32_t w = psi[(int64_t)(e / g.epw) * plane + off];
+    return (int)((w >> ((e % g.epw) * g.bits)) & ((1u << g.bits) - 1u));
+}
+
+// one backward step of the path: state (a,k) at time t (a = -1: silent) -> state at t-1, given
+// the offset of sample t in the transposed psi array
+__device__ __forceinline__ void walk_step(const RingGeom &g, const uint32_t *__restrict__ psi,
+                                          int64_t off, int &a, int &k)
+{
+    if (a >= 0 && k > 1) { k--; return; }  // ring interior: single predecessor
+    const int p = psi_get(g, psi, (int64_t)g.B * g.ncol, off, a + 1);
+    if (p == 0) { a = -1; k = 0; }
+    else { a = p - 1; k = g.L; }
+}
+
+// Backtrace (viterbi.jl:93-94).  Chain c starts its walk H samples after its own end (from the
+// silent state; from the true final state when that point is the end of the data); by the time
+// the walk enters the chain it has merged with the true path.  bstate[c] records the walk's
+// state on the first sample of chain c+1 for the stitch check.  The psi words of a step do not
+// depend on the walk's state, so they are fetched a batch ahead.
+template <int N>
+__global__ __launch_bounds__(64) void k_vit_backtrace(RingGeom g, const uint32_t *__restrict__ psi,
+                                                      const int32_t *__restrict__ final_state,
+                                                      int16_t *__restrict__ xT,
+                                                      int32_t *__restrict__ bstate)
+{
+    constexpr int BITS = psi_bits_c(N), EPW = psi_epw_c(N), W = psi_words_c(N), UB = 8;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const bool active = c < g.nch;
+    const int B = g.B, L = g.L, ncol = g.ncol;
+    const int64_t tc = (int64_t)c * B;
+    const int nc = active ? (int)((g.T - tc) < B ? (g.T - tc) : B) : 0;
+    int64_t te = tc + nc + g.H;
+    if (te > g.T) te = g.T;
+    const int se = (int)(te - 1 - tc);  // first (highest) step of this lane's walk
+    int a = -1, k = 0;
+    if (active && te == g.T) {
+        const int fs = final_state[0];
+        if (fs > 0) { a = (fs - 1) / L; k = (fs - 1) % L + 1; }
+    }
+    const int64_t plane = (int64_t)B * ncol;
+    auto load = [&](uint32_t(&d)[UB][W], int sb) {  // steps sb, sb-1, ..., sb-UB+1
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int s = sb - u;
+            const bool need = active && s <= se && s >= 0 && (tc + s) >= 1;
+#pragma unroll
+            for (int w = 0; w < W; w++) d[u][w] = 0u;
+            if (need) {
+                const int64_t off = (s < B) ? (int64_t)s * ncol + c : (int64_t)(s - B) * ncol + c + 1;
+#pragma unroll
+                for (int w = 0; w < W; w++) d[u][w] = psi[w * plane + off];
+            }
+        }
+    };
+    uint32_t cur[UB][W], nxt[UB][W];
+    const int stop = B + g.H - 1;  // wave-uniform start (H <= B, so s - B < B)
+    load(cur, stop);
+    for (int sb = stop; sb >= 0; sb -= UB) {
+        if (sb - UB >= 0) load(nxt, sb - UB);
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int s = sb - u;
+            if (active && s <= se && s >= 0) {
+                const int id = (a < 0) ? 1 : 2 + a * L + (k - 1);
+                if (s < nc) xT[(int64_t)s * ncol + c] = (int16_t)id;
+                if (s == nc) bstate[c] = id;
+                if (tc + s >= 1) {
+                    if (a >= 0 && k > 1) {
+                        k--;
+                    } else {
+                        const int e = a + 1;
+                        uint32_t wsel = cur[u][0];
+#pragma unroll
+                        for (int w = 1; w < W; w++) wsel = (e / EPW == w) ? cur[u][w] : wsel;
+                        const int p = (int)((wsel >> ((e % EPW) * BITS)) & ((1u << BITS) - 1u));
+                        if (p == 0) { a = -1; k = 0; }
+                        else { a = p - 1; k = L; }
+                    }
+                }
+            }
+        }
+        if (sb - UB >= 0) {
+#pragma unroll
+            for (int u = 0; u < UB; u++)
+#pragma unroll
+                for (int w = 0; w < W; w++) cur[u][w] = nxt[u][w];
+        }
+    }
+}
+
+// Stitch check: the state chain c's walk had on the first sample of chain c+1 must equal what
+// chain c+1 emitted there; otherwise chain c is queued for a re-walk.
+__global__ void k_stitch_check(RingGeom g, const int16_t *__restrict__ xT,
+                               const int32_t *__restrict__ bstate, int32_t *__restrict__ redo)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.nch - 1) return;
+    if (bstate[c] != (int)xT[c + 1]) {  // row 0, column c+1
+        const int slot = atomicAdd(&redo[0], 1);
+        if (slot < g.ncol) redo[1 + slot] = c;
+    }
+}
+
+// Serial repair of queued chains (rare): re-walk chain c from the state chain c+1 emitted on its
+// first sample, then cascade downwards while the junction with the previous chain disagrees.
+__global__ void k_stitch_fix(RingGeom g, const uint32_t *__restrict__ psi, int16_t *__restrict__ xT,
+                             int32_t *__restrict__ bstate, const int32_t *__restrict__ redo,
+                             int64_t *__restrict__ diag)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = redo[0] < g.ncol ? redo[0] : g.ncol;
+    const int B = g.B, L = g.L;
+    int64_t fixes = 0;
+    for (int i = 0; i < n; i++) {
+        int c = redo[1 + i];
+        while (c >= 0) {
+            const int want = xT[c + 1];
+            if (bstate[c] == want) break;
+            bstate[c] = want;
+            fixes++;
+            int a = -1, k = 0;
+            if (want > 1) { a = (want - 2) / L; k = (want - 2) % L + 1; }
+            const int64_t tc = (int64_t)c * B;
+            int64_t t = tc + B;  // first sample of chain c+1 (chain c < nch-1 is full length)
+            walk_step(g, psi, (int64_t)c + 1, a, k);  // row 0, column c+1
+            for (t = t - 1; t >= tc; t--) {
+                const int id = (a < 0) ? 1 : 2 + a * L + (k - 1);
+                xT[(t - tc) * g.ncol + c] = (int16_t)id;
+                if (t == 0) break;
+                if (t > tc) walk_step(g, psi, (t - tc) * g.ncol + c, a, k);
+            }
+            c--;  // did the first sample of chain c change?  then chain c-1 must be re-checked
+        }
+    }
+    diag[1] += fixes;
+}
+
+// Boundary check of the forward warm-up: the back-pointers chain c computed over the last Lc
+// warm-up samples must equal the ones chain c-1 computed for the same samples.
+__global__ void k_halo_check(RingGeom g, const uint32_t *__restrict__ psi,
+                             const uint32_t *__restrict__ psiH, int64_t *__restrict__ diag)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < 1 || c >= g.nch) return;
+    const int64_t tc = (int64_t)c * g.B;
+    int bad = 0;
+    for (int i = 0; i < g.Lc; i++) {
+        const int64_t t = tc - g.Lc + i;
+        if (t < 1 || -g.Lc + i < -g.H + 2 * g.L) continue;  // skip the warm-up's own start-up
+        const int64_t om = (t % g.B) * g.ncol + (t / g.B);
+        const int64_t oh = (int64_t)i * g.ncol + c;
+        for (int w = 0; w < g.W; w++)
+            bad |= psi[(int64_t)w * g.B * g.ncol + om] != psiH[(int64_t)w * g.Lc * g.ncol + oh];
+    }
+    if (bad) atomicAdd((unsigned long long *)&diag[0], 1ull);
+}
+
+// xT[s*ncol + c] -> x[c*B + s]
+__global__ __launch_bounds__(256) void k_transpose_x(const int16_t *__restrict__ xT, int64_t T,
+                                                     int B, int ncol, int16_t *__restrict__ x)
+{
+    __shared__ int16_t tile[64][66];
+    const int s0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int sl = ty + 4 * i;
+        tile[sl][tx] = xT[(int64_t)(s0 + sl) * ncol + c0 + tx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int cl = ty + 4 * i;
+        const int64_t t = (int64_t)(c0 + cl) * B + s0 + tx;
+        if (t < T) x[t] = tile[tx][cl];
+    }
+}
+
+// ll = sum_{t=1..T-1} T1[x_t, t]  (viterbi.jl:92-96), computed without the trellis:
+//   T1[x_t,t] = T1[x_0,0] + sum_{u=1..t} inc_u,  inc_u = lp(x_{u-1}->x_u) + q_u(x_u)
+//   => ll = (T-1)*T1[x_0,0] + sum_{u=1..T-1} (T-u)*inc_u        (a plain parallel reduction).
+// ctab: c00 | c0[N] | cend[N] | cx[N*N] | cint[N*L]
+__device__ __forceinline__ double path_lp(const RingGeom &g, const double *__restrict__ ctab,
+                                          int xp, int xc)
+{
+    const int N = g.N, L = g.L;
+    if (xp == 1) return xc == 1 ? ctab[0] : ctab[1 + (xc - 2) / L];
+    const int a = (xp - 2) / L, k = (xp - 2) % L + 1;
+    if (k < L) return ctab[1 + 2 * N + N * N + a * L + k];
+    if (xc == 1) return ctab[1 + N + a];
+    return ctab[1 + 2 * N + a * N + (xc - 2) / L];
+}
+
+__global__ __launch_bounds__(256) void k_ll_partial(RingGeom g, const double *__restrict__ y,
+                                                    const int16_t *__restrict__ x,
+                                                    const double *__restrict__ mean,
+                                                    const double *__restrict__ ctab, double A,
+                                                    double den, double *__restrict__ part)
+{
+    __shared__ double red[4];
+    const int64_t T = g.T;
+    double acc = 0.0;
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; u < T;
+         u += (int64_t)gridDim.x * blockDim.x) {
+        const int xp = x[u - 1], xc = x[u];
+        const double d = y[u] - mean[xc - 1];
+        const double inc = path_lp(g, ctab, xp, xc) + (A - (d * d) / den);
+        acc += (double)(T - u) * inc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int x0 = x[0];
+        if (x0 != 1) {  // T1[1,1] = 0 for the silent state (viterbi.jl:63)
+            const double d = y[0] - mean[x0 - 1];
+            acc += (double)(T - 1) * (A - (d * d) / den);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ part, int n,
+                                                      double *__restrict__ out)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += part[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int N>
+static JParams<N> make_jparams(const RingDev *r)
+{
+    JParams<N> p;
+    p.c00 = r->ring.c00;
+    for (int a = 0; a < N; a++) {
+        p.c0[a] = r->ring.c0[a];
+        p.cend[a] = r->ring.cend[a];
+        for (int b = 0; b < N; b++) p.cx[a * N + b] = r->ring.cx[a * N + b];
+    }
+    p.mean0 = r->mean[0];
+    p.den = r->den;
+    p.A = r->A;
+    return p;
+}
+
+int ring_viterbi_launch(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st)
+{
+    const RingGeom &g = r->g;
+    int rc;
+    HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
+    HS_HIP(hipMemsetAsync(r->redo, 0, sizeof(int32_t), st));
+    if ((rc = ring_launch_transpose_in(r, d_y, st))) return rc;
+    if ((rc = ring_launch_prepass(r, st))) return rc;
+    if ((rc = ring_launch_virtual(r, d_y, r->P, (int64_t)(g.H + g.B) * g.ncol, st))) return rc;
+    rc = dispatch_N(g.N, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        JParams<N> jp = make_jparams<N>(r);
+        hipLaunchKernelGGL((k_vit_chain<N>), dim3(g.ncol / 64), dim3(64), 0, st, g, jp, r->yT,
+                           r->Rf, r->P, r->psi, r->psiH, r->D0end);
+        HS_HIP(hipGetLastError());
+        return HMMSORT_OK;
+    });
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_vit_tail, dim3(1), dim3(64), 0, st, g, r->P, r->D0end, r->final_state);
+    rc = dispatch_N(g.N, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        hipLaunchKernelGGL((k_vit_backtrace<N>), dim3(g.ncol / 64), dim3(64), 0, st, g, r->psi,
+                           r->final_state, r->xT, r->bstate);
+        HS_HIP(hipGetLastError());
+        return HMMSORT_OK;
+    });
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_stitch_check, dim3((g.nch + 255) / 256), dim3(256), 0, st, g, r->xT,
+                       r->bstate, r->redo);
+    hipLaunchKernelGGL(k_stitch_fix, dim3(1), dim3(64), 0, st, g, r->psi, r->xT, r->bstate, r->redo,
+                       r->diag);
+    hipLaunchKernelGGL(k_halo_check, dim3((g.nch + 255) / 256), dim3(256), 0, st, g, r->psi,
+                       r->psiH, r->diag);
+    hipLaunchKernelGGL(k_transpose_x, dim3(g.B / 64, g.ncol / 64), dim3(256), 0, st, r->xT, g.T,
+                       g.B, g.ncol, d_x);
+    hipLaunchKernelGGL(k_ll_partial, dim3(r->nparts), dim3(256), 0, st, g, d_y, d_x, r->d_mean,
+                       r->d_ctab, r->A, r->den, r->part);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, r->part, r->nparts, d_ll);
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+}  // namespace hmmsort
