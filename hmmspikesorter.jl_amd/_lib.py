@@ -72,6 +72,14 @@ def lib():
                 "libhmmsort_hip.so is not built (%s). Build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C %s/csrc`; "
                 "there is no CPU fallback." % (LIB_PATH, _HERE))
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7 and fails to
+        # find the GPU if the system copy (same soname) was mapped first.  Importing torch first
+        # makes this library bind to the runtime torch uses; without torch the system ROCm copy
+        # (RUNPATH /opt/rocm/lib) is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here == header/library mismatch
