@@ -84,7 +84,10 @@ struct RingDev {
     int32_t *final_state = nullptr;
     double *part = nullptr;       // reduction partials
     double *Zc = nullptr;         // ncol per-chain normalisers
-    double *stats_part = nullptr; // E-step partial sums
+    double *B0h = nullptr;        // ncol: bwd silent value one step past the chain (warm-up side)
+    double *partA = nullptr;      // nparts x 3 x NLpad per-block ring-state sums
+    double *partS = nullptr;      // nparts x (N+4) per-block scalar sums
+    double *pp = nullptr;         // S: gamma[:,1] in the log domain
     int64_t *diag = nullptr;      // 8 device counters
     int64_t bytes = 0;
     int nparts = 0;

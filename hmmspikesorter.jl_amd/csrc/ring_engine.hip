@@ -133,7 +133,10 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T)
     A(&r->final_state, 8);
     A(&r->part, 4 * r->nparts);
     A(&r->Zc, g.ncol);
-    A(&r->stats_part, (int64_t)r->nparts * (3 * N * L + 8 + 2 * N));
+    A(&r->B0h, g.ncol);
+    A(&r->partA, (int64_t)r->nparts * 3 * ((N * L + 255) / 256 * 256));
+    A(&r->partS, (int64_t)r->nparts * (N + 4));
+    A(&r->pp, m.S);
     A(&r->diag, 8);
     if (!ok) { ring_destroy(r); return HMMSORT_ENOMEM; }
     if (hipMemset(r->diag, 0, 8 * sizeof(int64_t)) != hipSuccess) { ring_destroy(r); return HMMSORT_EHIP; }
@@ -148,7 +151,7 @@ void ring_destroy(RingDev *r)
     if (!r) return;
     void *ptrs[] = {r->d_mean, r->d_cint, r->d_ctab, r->d_states, r->yT, r->Rf, r->P, r->Q, r->A0,
                     r->B0, r->psi, r->psiH, r->D0end, r->bstate, r->redo, r->xT, r->final_state,
-                    r->part, r->Zc, r->stats_part, r->diag};
+                    r->part, r->Zc, r->B0h, r->partA, r->partS, r->pp, r->diag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete r;
