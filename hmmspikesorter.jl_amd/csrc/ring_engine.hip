@@ -2,6 +2,7 @@
 // Design notes: ring_common.h / DESIGN.md.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 #include "ring_common.h"
@@ -139,6 +140,21 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T)
     A(&r->pp, m.S);
     A(&r->diag, 8);
     if (!ok) { ring_destroy(r); return HMMSORT_ENOMEM; }
+    if (getenv("HMMSORT_POISON")) {
+        // test aid: fill the work arrays with NaN bit patterns so that a kernel reading an
+        // element nobody wrote shows up as NaN instead of depending on stale memory
+        (void)hipMemset(r->P, 0xFF, N * (int64_t)(g.H + g.B) * g.ncol * 8);
+        (void)hipMemset(r->Q, 0xFF, N * (int64_t)(g.L + g.B + g.H) * g.ncol * 8);
+        (void)hipMemset(r->A0, 0xFF, (int64_t)(1 + g.B) * g.ncol * 8);
+        (void)hipMemset(r->B0, 0xFF, BC * 8);
+        (void)hipMemset(r->Rf, 0xFF, N * BC * 8);
+        (void)hipMemset(r->yT, 0xFF, BC * 8);
+        (void)hipMemset(r->psi, 0xFF, (int64_t)g.W * BC * 4);
+        (void)hipMemset(r->xT, 0xFF, BC * 2);
+        (void)hipMemset(r->Zc, 0xFF, g.ncol * 8);
+        (void)hipMemset(r->partA, 0xFF, (int64_t)r->nparts * 3 * ((N * L + 255) / 256 * 256) * 8);
+        (void)hipMemset(r->partS, 0xFF, (int64_t)r->nparts * (N + 4) * 8);
+    }
     if (hipMemset(r->diag, 0, 8 * sizeof(int64_t)) != hipSuccess) { ring_destroy(r); return HMMSORT_EHIP; }
     rc = ring_set_model(r, m);
     if (rc) { ring_destroy(r); return rc; }

@@ -193,6 +193,13 @@ __global__ __launch_bounds__(64) void k_bwd_chain(RingGeom g, EParams<N> ep,
                     lb0 = 0.0;
 #pragma unroll
                     for (int a = 0; a < N; a++) Yn[a] = 0.0;
+                    // onsets whose ring runs past te: ly = 0 (rows the sweep below never writes,
+                    // read by the statistics kernels when te is the end of the data)
+                    for (int i = 2; i <= L; i++) {
+                        const int64_t o = (int64_t)(s + i) * ncol + c;
+#pragma unroll
+                        for (int a = 0; a < N; a++) Q[a * planeQ + o] = 0.0;
+                    }
                 } else {
                     const double d = cur[u].y - ep.mean0;
                     const double v0 = lb0 - (d * d) / ep.den;
@@ -328,6 +335,7 @@ __global__ __launch_bounds__(256) void k_stats(RingGeom g, StatsCfg cfg, JParams
                 const int64_t rem = T - ((int64_t)(c0 + tid) * B + r0);
                 vlen[tid] = rem < 0 ? 0 : (rem > WY ? WY : (int)rem);
             }
+            __syncthreads();
             // phase 1: rows r0 + wv, r0 + wv + 4, ...
             for (int rr = wv; rr < TR; rr += 4) {
                 const int s = r0 + rr;

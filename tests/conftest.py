@@ -4,6 +4,7 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("HMMSORT_POISON", "1")  # NaN-fill GPU work arrays (catches unwritten reads)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
