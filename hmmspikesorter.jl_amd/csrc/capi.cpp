@@ -6,6 +6,7 @@
 #include <mutex>
 
 #include "hmmsort_internal.h"
+#include "ring_common.h"
 
 using namespace hmmsort;
 
@@ -241,6 +242,39 @@ int hmmsort_plan_diagnostics(hmmsort_plan *p, void *stream, int64_t diag[8])
     HS_CHECK(p && diag, HMMSORT_EINVAL, "plan_diagnostics: null argument");
     for (int i = 0; i < 8; i++) diag[i] = 0;
     if (p->ring) return ring_diagnostics(p->ring, (hipStream_t)stream, diag);
+    return HMMSORT_OK;
+}
+
+int hmmsort_plan_profile(hmmsort_plan *p, int enable)
+{
+    HS_CHECK(p, HMMSORT_EINVAL, "plan_profile: null plan");
+    if (p->ring) return ring_profile_enable(p->ring, enable);
+    return HMMSORT_OK;
+}
+
+int hmmsort_plan_profile_read(hmmsort_plan *p, void *stream, char *names, int64_t names_cap,
+                              double *ms, int64_t *calls, int64_t cap, int64_t *n_out)
+{
+    HS_CHECK(p && names && ms && calls && n_out, HMMSORT_EINVAL, "plan_profile_read: null argument");
+    *n_out = 0;
+    if (names_cap > 0) names[0] = 0;
+    if (!p->ring) return HMMSORT_OK;
+    std::vector<std::string> nm;
+    std::vector<double> m;
+    std::vector<int64_t> c;
+    int rc = ring_profile_read(p->ring, (hipStream_t)stream, nm, m, c);
+    if (rc) return rc;
+    std::string joined;
+    int64_t n = std::min<int64_t>((int64_t)nm.size(), cap);
+    for (int64_t i = 0; i < n; i++) {
+        if (i) joined += "\n";
+        joined += nm[i];
+        ms[i] = m[i];
+        calls[i] = c[i];
+    }
+    HS_CHECK((int64_t)joined.size() + 1 <= names_cap, HMMSORT_EINVAL, "plan_profile_read: names buffer too small");
+    memcpy(names, joined.c_str(), joined.size() + 1);
+    *n_out = n;
     return HMMSORT_OK;
 }
 

@@ -16,6 +16,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string>
+#include <vector>
 
 #include "hmmsort_internal.h"
 
@@ -57,8 +59,16 @@ struct EParams {
     double den;
 };
 
+// optional per-kernel timing with HIP events on the caller's stream (bench.py / profiling)
+struct ProfEntry {
+    const char *name;
+    hipEvent_t a, b;
+};
+
 struct RingDev {
     RingGeom g{};
+    bool prof_on = false;
+    std::vector<ProfEntry> prof;
     int64_t S = 0, K = 0;
     double sigma = 0, lsig = 0, A = 0, den = 0;
     RingModel ring;               // host copy of the transition constants
@@ -92,6 +102,26 @@ struct RingDev {
     int64_t bytes = 0;
     int nparts = 0;
 };
+
+struct ProfScope {
+    RingDev *r;
+    hipStream_t st;
+    ProfEntry e;
+    ProfScope(RingDev *r_, const char *name, hipStream_t st_) : r(r_), st(st_)
+    {
+        e.name = name; e.a = nullptr; e.b = nullptr;
+        if (r->prof_on && hipEventCreate(&e.a) == hipSuccess && hipEventCreate(&e.b) == hipSuccess)
+            (void)hipEventRecord(e.a, st);
+    }
+    ~ProfScope()
+    {
+        if (r->prof_on && e.a && e.b) {
+            (void)hipEventRecord(e.b, st);
+            r->prof.push_back(e);
+        }
+    }
+};
+#define PROF(r, name, st) ProfScope prof_scope_(r, name, st)
 
 template <typename F>
 inline int dispatch_N(int N, F &&f)
@@ -138,5 +168,8 @@ int ring_launch_transpose_in(RingDev *r, const double *d_y, hipStream_t st);
 int ring_launch_prepass(RingDev *r, hipStream_t st);
 int ring_launch_virtual(RingDev *r, const double *d_y, double *dst_planes, int64_t plane_stride,
                         hipStream_t st);
+int ring_profile_enable(RingDev *r, int on);
+int ring_profile_read(RingDev *r, hipStream_t st, std::vector<std::string> &names,
+                      std::vector<double> &ms, std::vector<int64_t> &calls);
 
 }  // namespace hmmsort

@@ -214,8 +214,8 @@ __global__ __launch_bounds__(256) void k_transpose_in(const double *__restrict__
 int ring_launch_transpose_in(RingDev *r, const double *d_y, hipStream_t st)
 {
     const RingGeom &g = r->g;
-    hipLaunchKernelGGL(k_transpose_in, dim3(g.B / 64, g.ncol / 64), dim3(256), 0, st, d_y, g.T, g.B,
-                       g.ncol, r->yT);
+    { PROF(r, "k_transpose_in", st); hipLaunchKernelGGL(k_transpose_in, dim3(g.B / 64, g.ncol / 64), dim3(256), 0, st, d_y, g.T, g.B,
+                       g.ncol, r->yT); }
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }
@@ -287,8 +287,8 @@ int ring_launch_prepass(RingDev *r, hipStream_t st)
     return dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
         constexpr int RS = prepass_rows<N>();
-        hipLaunchKernelGGL((k_prepass<N>), dim3(g.ncol / 64, g.B / (4 * RS)), dim3(256), 0, st, g,
-                           r->yT, r->d_mean, r->d_cint, r->den, r->Rf);
+        { PROF(r, "k_prepass", st); hipLaunchKernelGGL((k_prepass<N>), dim3(g.ncol / 64, g.B / (4 * RS)), dim3(256), 0, st, g,
+                           r->yT, r->d_mean, r->d_cint, r->den, r->Rf); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
     });
@@ -326,9 +326,37 @@ __global__ void k_virtual(RingGeom g, const double *__restrict__ y, const double
 int ring_launch_virtual(RingDev *r, const double *d_y, double *dst, int64_t plane_stride,
                         hipStream_t st)
 {
-    hipLaunchKernelGGL(k_virtual, dim3(1), dim3(256), 0, st, r->g, d_y, r->d_mean, r->d_cint, r->den,
-                       dst, plane_stride);
+    { PROF(r, "k_virtual", st); hipLaunchKernelGGL(k_virtual, dim3(1), dim3(256), 0, st, r->g, d_y, r->d_mean, r->d_cint, r->den,
+                       dst, plane_stride); }
     HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+int ring_profile_enable(RingDev *r, int on)
+{
+    r->prof_on = on != 0;
+    return HMMSORT_OK;
+}
+
+// Synchronises the stream; returns per-kernel-name total milliseconds and call counts since the
+// last read.
+int ring_profile_read(RingDev *r, hipStream_t st, std::vector<std::string> &names,
+                      std::vector<double> &ms, std::vector<int64_t> &calls)
+{
+    HS_HIP(hipStreamSynchronize(st));
+    for (auto &e : r->prof) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) t = 0.f;
+        size_t i = 0;
+        for (; i < names.size(); i++)
+            if (names[i] == e.name) break;
+        if (i == names.size()) { names.push_back(e.name); ms.push_back(0.0); calls.push_back(0); }
+        ms[i] += t;
+        calls[i] += 1;
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    r->prof.clear();
     return HMMSORT_OK;
 }
 

@@ -564,34 +564,34 @@ int ring_estep_launch(RingDev *r, const double *d_y, double *d_stats, hipStream_
         constexpr int NN = decltype(n)::value;
         EParams<NN> ep = make_eparams<NN>(r);
         JParams<NN> jp = make_jparams_e<NN>(r);
-        hipLaunchKernelGGL((k_fwd_chain<NN>), dim3(g.ncol / 64), dim3(64), 0, st, g, ep, r->yT, r->Rf,
-                           r->P, r->A0);
-        hipLaunchKernelGGL((k_bwd_chain<NN>), dim3(g.ncol / 64), dim3(64), 0, st, g, ep, r->yT, r->Rf,
-                           r->Q, r->B0, r->B0h);
-        hipLaunchKernelGGL(k_znorm, dim3((g.nch + 63) / 64), dim3(64), 0, st, g, r->P, r->Q, r->A0,
-                           r->B0, r->Zc);
+        { PROF(r, "k_fwd_chain", st); hipLaunchKernelGGL((k_fwd_chain<NN>), dim3(g.ncol / 64), dim3(64), 0, st, g, ep, r->yT, r->Rf,
+                           r->P, r->A0); }
+        { PROF(r, "k_bwd_chain", st); hipLaunchKernelGGL((k_bwd_chain<NN>), dim3(g.ncol / 64), dim3(64), 0, st, g, ep, r->yT, r->Rf,
+                           r->Q, r->B0, r->B0h); }
+        { PROF(r, "k_znorm", st); hipLaunchKernelGGL(k_znorm, dim3((g.nch + 63) / 64), dim3(64), 0, st, g, r->P, r->Q, r->A0,
+                           r->B0, r->Zc); }
         const size_t lds = lds_bytes(cfg.TR);
         if (lds > 64 * 1024)
             HS_HIP(hipFuncSetAttribute((const void *)k_stats<NN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_stats<NN>), dim3(gx, ngroups), dim3(256), lds, st, g, cfg, jp, d_y,
-                           r->Rf, r->P, r->Q, r->A0, r->B0, r->Zc, r->partA, r->partS);
+        { PROF(r, "k_stats", st); hipLaunchKernelGGL((k_stats<NN>), dim3(gx, ngroups), dim3(256), lds, st, g, cfg, jp, d_y,
+                           r->Rf, r->P, r->Q, r->A0, r->B0, r->Zc, r->partA, r->partS); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
     });
     if (rc) return rc;
-    hipLaunchKernelGGL(k_stats_virtual, dim3(1), dim3(256), 0, st, g, cfg.NLpad, gx, d_y, r->P, r->Q,
-                       r->A0, r->B0, r->Zc, r->partA, r->pp);
+    { PROF(r, "k_stats_virtual", st); hipLaunchKernelGGL(k_stats_virtual, dim3(1), dim3(256), 0, st, g, cfg.NLpad, gx, d_y, r->P, r->Q,
+                       r->A0, r->B0, r->Zc, r->partA, r->pp); }
     const int total = 3 * NL + N + 4;
-    hipLaunchKernelGGL(k_stats_reduce, dim3((total + 255) / 256), dim3(256), 0, st, NL, cfg.NLpad, N,
-                       gx + 1, gx, r->partA, r->partS, d_stats);
+    { PROF(r, "k_stats_reduce", st); hipLaunchKernelGGL(k_stats_reduce, dim3((total + 255) / 256), dim3(256), 0, st, NL, cfg.NLpad, N,
+                       gx + 1, gx, r->partA, r->partS, d_stats); }
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }
 
 int ring_mstep_launch(RingDev *r, const double *d_stats, double *d_out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_mstep, dim3(1), dim3(256), 0, st, r->g.N, r->g.L, d_stats, r->pp, d_out);
+    { PROF(r, "k_mstep", st); hipLaunchKernelGGL(k_mstep, dim3(1), dim3(256), 0, st, r->g.N, r->g.L, d_stats, r->pp, d_out); }
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }

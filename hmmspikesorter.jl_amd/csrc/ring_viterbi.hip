@@ -446,32 +446,32 @@ int ring_viterbi_launch(RingDev *r, const double *d_y, int16_t *d_x, double *d_l
     rc = dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
         JParams<N> jp = make_jparams<N>(r);
-        hipLaunchKernelGGL((k_vit_chain<N>), dim3(g.ncol / 64), dim3(64), 0, st, g, jp, r->yT,
-                           r->Rf, r->P, r->psi, r->psiH, r->D0end);
+        { PROF(r, "k_vit_chain", st); hipLaunchKernelGGL((k_vit_chain<N>), dim3(g.ncol / 64), dim3(64), 0, st, g, jp, r->yT,
+                           r->Rf, r->P, r->psi, r->psiH, r->D0end); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
     });
     if (rc) return rc;
-    hipLaunchKernelGGL(k_vit_tail, dim3(1), dim3(64), 0, st, g, r->P, r->D0end, r->final_state);
+    { PROF(r, "k_vit_tail", st); hipLaunchKernelGGL(k_vit_tail, dim3(1), dim3(64), 0, st, g, r->P, r->D0end, r->final_state); }
     rc = dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
-        hipLaunchKernelGGL((k_vit_backtrace<N>), dim3(g.ncol / 64), dim3(64), 0, st, g, r->psi,
-                           r->final_state, r->xT, r->bstate);
+        { PROF(r, "k_vit_backtrace", st); hipLaunchKernelGGL((k_vit_backtrace<N>), dim3(g.ncol / 64), dim3(64), 0, st, g, r->psi,
+                           r->final_state, r->xT, r->bstate); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
     });
     if (rc) return rc;
-    hipLaunchKernelGGL(k_stitch_check, dim3((g.nch + 255) / 256), dim3(256), 0, st, g, r->xT,
-                       r->bstate, r->redo);
-    hipLaunchKernelGGL(k_stitch_fix, dim3(1), dim3(64), 0, st, g, r->psi, r->xT, r->bstate, r->redo,
-                       r->diag);
-    hipLaunchKernelGGL(k_halo_check, dim3((g.nch + 255) / 256), dim3(256), 0, st, g, r->psi,
-                       r->psiH, r->diag);
-    hipLaunchKernelGGL(k_transpose_x, dim3(g.B / 64, g.ncol / 64), dim3(256), 0, st, r->xT, g.T,
-                       g.B, g.ncol, d_x);
-    hipLaunchKernelGGL(k_ll_partial, dim3(r->nparts), dim3(256), 0, st, g, d_y, d_x, r->d_mean,
-                       r->d_ctab, r->A, r->den, r->part);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, r->part, r->nparts, d_ll);
+    { PROF(r, "k_stitch_check", st); hipLaunchKernelGGL(k_stitch_check, dim3((g.nch + 255) / 256), dim3(256), 0, st, g, r->xT,
+                       r->bstate, r->redo); }
+    { PROF(r, "k_stitch_fix", st); hipLaunchKernelGGL(k_stitch_fix, dim3(1), dim3(64), 0, st, g, r->psi, r->xT, r->bstate, r->redo,
+                       r->diag); }
+    { PROF(r, "k_halo_check", st); hipLaunchKernelGGL(k_halo_check, dim3((g.nch + 255) / 256), dim3(256), 0, st, g, r->psi,
+                       r->psiH, r->diag); }
+    { PROF(r, "k_transpose_x", st); hipLaunchKernelGGL(k_transpose_x, dim3(g.B / 64, g.ncol / 64), dim3(256), 0, st, r->xT, g.T,
+                       g.B, g.ncol, d_x); }
+    { PROF(r, "k_ll_partial", st); hipLaunchKernelGGL(k_ll_partial, dim3(r->nparts), dim3(256), 0, st, g, d_y, d_x, r->d_mean,
+                       r->d_ctab, r->A, r->den, r->part); }
+    { PROF(r, "k_sum_partials", st); hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, r->part, r->nparts, d_ll); }
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }

@@ -70,3 +70,18 @@ class Plan:
         d = (C.c_int64 * 8)()
         check(lib().hmmsort_plan_diagnostics(self._h, C.c_void_p(stream), d))
         return list(d)
+
+    def profile(self, enable=True):
+        check(lib().hmmsort_plan_profile(self._h, int(bool(enable))))
+
+    def profile_read(self, stream=0):
+        """{kernel name: (total ms, launches)} since the previous read (synchronises the stream)."""
+        cap = 64
+        names = C.create_string_buffer(4096)
+        ms = (C.c_double * cap)()
+        calls = (C.c_int64 * cap)()
+        n = C.c_int64(0)
+        check(lib().hmmsort_plan_profile_read(self._h, C.c_void_p(stream), names, 4096, ms, calls,
+                                              cap, C.byref(n)))
+        nm = names.value.decode().split("\n") if n.value else []
+        return {nm[i]: (ms[i], calls[i]) for i in range(n.value)}

@@ -150,8 +150,7 @@ int hmmsort_plan_viterbi(hmmsort_plan *plan, const double *d_y, int16_t *d_x, do
 /* E-step: forward-backward + sufficient statistics.  d_stats receives
  * hmmsort_plan_stats_len() doubles (layout: hmmsort_plan_stats_layout below); the vector is a
  * plain sum over time, so shards of one recording / pooled channels combine by a SUM
- * all-reduce (RCCL) before the M-step.  `first`/`last` tell whether this shard starts at the
- * true beginning / ends at the true end of the recording (both 1 for a whole recording). */
+ * all-reduce (RCCL) before the M-step. */
 int hmmsort_plan_estep(hmmsort_plan *plan, const double *d_y, double *d_stats, void *stream);
 int64_t hmmsort_plan_stats_len(const hmmsort_plan *plan);
 /* M-step finish from (all-reduced) statistics, on device: d_out receives
@@ -162,6 +161,15 @@ int hmmsort_plan_mstep(hmmsort_plan *plan, const double *d_stats, double *d_out,
  * diag[1] = number of backtrace stitch repairs, diag[2] = halo escalations,
  * diag[3] = forward-backward boundary failures. */
 int hmmsort_plan_diagnostics(hmmsort_plan *plan, void *stream, int64_t diag[8]);
+
+/* Per-kernel timing of the ring engine with HIP events recorded on the caller's stream (used by
+ * bench.py for the roofline line).  hmmsort_plan_profile(plan, 1) switches bracketing on;
+ * hmmsort_plan_profile_read synchronises the stream and returns, per kernel name, the total
+ * milliseconds and the number of launches since the previous read.  `names` receives the kernel
+ * names joined by '\n'. */
+int hmmsort_plan_profile(hmmsort_plan *plan, int enable);
+int hmmsort_plan_profile_read(hmmsort_plan *plan, void *stream, char *names, int64_t names_cap,
+                              double *ms, int64_t *calls, int64_t cap, int64_t *n_out);
 
 #ifdef __cplusplus
 }
