@@ -4,7 +4,7 @@ viterbi, reconstruct_signal of grero/HMMSpikeSorter.jl) behind libhmmsort_hip.so
 The directory name is the one the build contract fixes; it is not a valid Python identifier, so
 import it through the root-level shim:  `import hmmsort_amd`.
 """
-from . import _lib, synth
+from . import _lib, dist, synth
 from ._lib import (ENGINE_AUTO, ENGINE_RING, ENGINE_STRICT, HmmsortError, device_count,
                    get_option, set_option)
 from .api import (HMMSpikeTemplateModel, HMMSpikingModel, StateMatrix, backward, fit, forward,

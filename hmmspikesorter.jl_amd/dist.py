@@ -1,0 +1,53 @@
+"""Multi-GPU host logic: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm,
+"gloo" in the CPU tests).
+
+* channels are independent units in the reference (src/hmmsort.jl:79-83): `shard_channels` deals
+  them round-robin; no collective on the data path;
+* training ONE model on several shards (time shards of a recording, or pooled channels -- the
+  latter is an extension the reference does not have) needs exactly one SUM all-reduce of the
+  E-step statistics per EM iteration: `allreduce_stats`, between Plan.estep and Plan.mstep.
+"""
+import numpy as np
+
+
+def shard_channels(n_channels, rank, world_size):
+    """Channel indices owned by `rank` (round-robin)."""
+    return list(range(rank, n_channels, world_size))
+
+
+def allreduce_stats(stats, group=None):
+    """In-place SUM all-reduce of a statistics vector (torch tensor on the rank's device)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    return stats
+
+
+def gather_results(local, n_channels, rank, world_size, group=None):
+    """Collect per-channel python objects on every rank, in channel order."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or world_size == 1:
+        return local
+    parts = [None] * world_size
+    dist.all_gather_object(parts, local, group=group)
+    out = [None] * n_channels
+    for r, items in enumerate(parts):
+        for ch, item in zip(shard_channels(n_channels, r, world_size), items):
+            out[ch] = item
+    return out
+
+
+def mstep_from_stats(stats, N, L):
+    """Host (numpy) evaluation of the M-step finish from a statistics vector with the layout of
+    hmmsort_plan_estep: [G0 | G1 | G2 | Xi | s_all | s_m | s_y2 | 0].  Only used to check the
+    all-reduce plumbing in CPU tests; the product M-step is Plan.mstep on the GPU."""
+    NL = N * L
+    G0, G1, G2 = stats[:NL], stats[NL:2 * NL], stats[2 * NL:3 * NL]
+    Xi = stats[3 * NL:3 * NL + N]
+    s_all, s_m, s_y2 = stats[3 * NL + N:3 * NL + N + 3]
+    mu = G1 / G0
+    x2 = np.sum((G2 - 2 * mu * G1) + mu * mu * G0) + s_y2
+    qq = np.sum(G0) + s_all
+    mu_full = np.zeros((L + 1, N), order="F")
+    mu_full[1:, :] = mu.reshape((N, L)).T
+    return mu_full, float(np.sqrt(x2 / qq)), np.log(Xi) - np.log(s_m)

@@ -1,0 +1,94 @@
+# HMMSpikeSorterHIP.jl -- drop-in overrides that route the hot path of HMMSpikeSorter.jl through
+# libhmmsort_hip.so (include/hmmsort.h).
+#
+# NOT EXERCISED IN THE BUILD IMAGE: no Julia runtime is installed there.  The Python host
+# (hmmspikesorter.jl_amd/api.py) binds the same entry points and is what the tests run.
+#
+# Usage:   using HMMSpikeSorter; include("HMMSpikeSorterHIP.jl"); HMMSpikeSorterHIP.enable!()
+# After enable!(), HMMSpikeSorter.viterbi / forward / backward / update /
+# train_model(X, sm, mu, sigma) / reconstruct_signal keep their signatures and return values
+# (reference src/viterbi.jl:44, src/baumwelch.jl:25,73,205,362, src/reconstruction.jl:1) but run on
+# the GPU.  Julia arrays are passed as they are: Matrix{Int16} states, Vector{Tuple{Int64,Int64,
+# Float64}} transitions (24-byte isbits records), column-major Float64 matrices.
+module HMMSpikeSorterHIP
+
+using HMMSpikeSorter
+import HMMSpikeSorter: StateMatrix
+
+const lib = get(ENV, "HMMSORT_LIB", "libhmmsort_hip.so")
+
+lasterror() = unsafe_string(ccall((:hmmsort_last_error, lib), Cstring, ()))
+check(rc) = rc == 0 || error("hmmsort error $rc: $(lasterror())")
+
+function viterbi(y::AbstractArray{Float64,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64)
+    yv = y isa Array ? y : collect(y)          # fit.jl:23 passes contiguous views
+    x = zeros(Int16, length(yv)); ll = Ref{Float64}(0.0)
+    check(ccall((:hmmsort_viterbi, lib), Cint,
+        (Ptr{Float64}, Int64, Ptr{Int16}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Float64,
+         Ptr{Int16}, Ref{Float64}),
+        yv, length(yv), lA.states, lA.N, lA.K, lA.nstates, lA.transitions, length(lA.transitions), μ, σ, x, ll))
+    x, ll[]
+end
+
+function _fb(sym, V, lA, μ, σ)
+    a = Array{Float64,2}(undef, lA.nstates, length(V))
+    check(ccall((sym, lib), Cint,
+        (Ptr{Float64}, Int64, Ptr{Int16}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Float64, Ptr{Float64}),
+        V, length(V), lA.states, lA.N, lA.K, lA.nstates, lA.transitions, length(lA.transitions), μ, σ, a))
+    a
+end
+forward(V::Array{Float64,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64) = _fb(:hmmsort_forward, V, lA, μ, σ)
+backward(V::Array{Float64,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64) = _fb(:hmmsort_backward, V, lA, μ, σ)
+
+function _finish(lA, μ, σnew, lp, nlp, pp)
+    # baumwelch.jl:265 -- the rebuilt StateMatrix is a genuine reference struct
+    lA_new = StateMatrix(lA.states .- one(Int16), pp, lA.K, lp[1:nlp[]]; allow_overlaps=lA.resolve_overlaps)
+    lA_new, μ, σnew[]
+end
+
+function update(α::Array{Float64,2}, β::Array{Float64,2}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64, x::Array{Float64,1})
+    σnew = Ref{Float64}(0.0); nlp = Ref{Int64}(0)
+    lp = zeros(length(lA.transitions)); pp = zeros(lA.nstates)
+    check(ccall((:hmmsort_update, lib), Cint,
+        (Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int16}, Int64, Int64, Int64, Ptr{Cvoid}, Int64,
+         Ptr{Float64}, Float64, Ref{Float64}, Ptr{Float64}, Int64, Ref{Int64}, Ptr{Float64}),
+        α, β, x, length(x), lA.states, lA.N, lA.K, lA.nstates, lA.transitions, length(lA.transitions),
+        μ, σ, σnew, lp, length(lp), nlp, pp))       # μ is overwritten in place (baumwelch.jl:268)
+    _finish(lA, μ, σnew, lp, nlp, pp)
+end
+
+# one EM step, baumwelch.jl:362-370: a single call, alpha/beta never leave the GPU
+function train_model(X::Array{Float64,1}, state_matrix::StateMatrix, μ0::Array{Float64,2}, σ0::Float64; verbose=0)
+    σnew = Ref{Float64}(0.0); nlp = Ref{Int64}(0)
+    lp = zeros(length(state_matrix.transitions)); pp = zeros(state_matrix.nstates)
+    check(ccall((:hmmsort_em_step, lib), Cint,
+        (Ptr{Float64}, Int64, Ptr{Int16}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Float64,
+         Ref{Float64}, Ptr{Float64}, Int64, Ref{Int64}, Ptr{Float64}),
+        X, length(X), state_matrix.states, state_matrix.N, state_matrix.K, state_matrix.nstates,
+        state_matrix.transitions, length(state_matrix.transitions), μ0, σ0, σnew, lp, length(lp), nlp, pp))
+    _finish(state_matrix, μ0, σnew, lp, nlp, pp)
+end
+
+function reconstruct_signal(x::Array{T,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64) where T <: Integer
+    xs = T === Int16 ? x : Int16.(x)
+    Y2 = zeros(Float64, length(xs))
+    check(ccall((:hmmsort_reconstruct, lib), Cint,
+        (Ptr{Int16}, Int64, Ptr{Int16}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}),
+        xs, length(xs), lA.states, lA.N, lA.nstates, μ, size(μ, 1), Y2))
+    Y2
+end
+
+"Replace the reference's method bodies by the GPU versions (same signatures)."
+function enable!()
+    @eval HMMSpikeSorter begin
+        viterbi(y::AbstractArray{Float64,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64) = $(viterbi)(y, lA, μ, σ)
+        forward(V::Array{Float64,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64) = $(forward)(V, lA, μ, σ)
+        backward(V::Array{Float64,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64) = $(backward)(V, lA, μ, σ)
+        update(α::Array{Float64,2}, β::Array{Float64,2}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64, x::Array{Float64,1}) = $(update)(α, β, lA, μ, σ, x)
+        train_model(X::Array{Float64,1}, sm::StateMatrix, μ0::Array{Float64,2}, σ0::Float64; verbose=0) = $(train_model)(X, sm, μ0, σ0; verbose=verbose)
+        reconstruct_signal(x::Array{T,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64) where T <: Integer = $(reconstruct_signal)(x, lA, μ, σ)
+    end
+    nothing
+end
+
+end # module
