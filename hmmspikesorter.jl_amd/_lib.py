@@ -54,6 +54,8 @@ SIGNATURES = {
     "hmmsort_plan_set_model": (_int, [_vp, _vp, _i64, _vp, _f64]),
     "hmmsort_plan_destroy": (_int, [_vp]),
     "hmmsort_plan_info": (_int, [_vp, _pi64, _pi64, _pi64, _pi64, _pi64]),
+    "hmmsort_plan_bind": (_int, [_vp, _vp, _vp]),
+    "hmmsort_plan_unbind": (_int, [_vp]),
     "hmmsort_plan_viterbi": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "hmmsort_plan_estep": (_int, [_vp, _vp, _vp, _vp]),
     "hmmsort_plan_stats_len": (_i64, [_vp]),

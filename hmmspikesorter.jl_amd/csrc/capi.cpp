@@ -207,6 +207,20 @@ int hmmsort_plan_info(const hmmsort_plan *p, int64_t *engine, int64_t *block, in
     return HMMSORT_OK;
 }
 
+int hmmsort_plan_bind(hmmsort_plan *p, const double *d_y, void *stream)
+{
+    HS_CHECK(p && d_y, HMMSORT_EINVAL, "plan_bind: null argument");
+    if (p->ring) return ring_bind(p->ring, d_y, (hipStream_t)stream);
+    return HMMSORT_OK;
+}
+
+int hmmsort_plan_unbind(hmmsort_plan *p)
+{
+    HS_CHECK(p, HMMSORT_EINVAL, "plan_unbind: null plan");
+    if (p->ring) p->ring->bound_y = nullptr;
+    return HMMSORT_OK;
+}
+
 int hmmsort_plan_viterbi(hmmsort_plan *p, const double *d_y, int16_t *d_x, double *d_ll,
                          void *stream)
 {

@@ -68,6 +68,7 @@ struct ProfEntry {
 struct RingDev {
     RingGeom g{};
     bool prof_on = false;
+    const double *bound_y = nullptr;  // signal whose yT/Rf are current (hmmsort_plan_bind)
     std::vector<ProfEntry> prof;
     int64_t S = 0, K = 0;
     double sigma = 0, lsig = 0, A = 0, den = 0;
@@ -75,6 +76,7 @@ struct RingDev {
     std::vector<double> mean;     // host copy of per-state means
     // device model tables
     double *d_mean = nullptr;     // S
+    double *d_msq = nullptr;      // N*(L+1): Msq[a][kk] = sum_{k=1}^{kk} mean(a,k)^2
     double *d_cint = nullptr;     // N*(L+1): Cint[a][kk] = sum_{k=1}^{kk-1} lp((a,k)->(a,k+1))
     double *d_ctab = nullptr;     // 1 + N + N + N*N + N*L: c00 | c0 | cend | cx | cint
     int16_t *d_states = nullptr;  // N x S (for the M-step pack)
@@ -95,8 +97,10 @@ struct RingDev {
     double *part = nullptr;       // reduction partials
     double *Zc = nullptr;         // ncol per-chain normalisers
     double *B0h = nullptr;        // ncol: bwd silent value one step past the chain (warm-up side)
-    double *partA = nullptr;      // nparts x 3 x NLpad per-block ring-state sums
-    double *partS = nullptr;      // nparts x (N+4) per-block scalar sums
+    double *partA = nullptr;      // (ncol/64) x 2 x N*L per-wave spike-triggered sums (G1 | G2)
+    double *partS = nullptr;      // (ncol/64) x (2N+3) per-wave scalar sums
+    double *rhoT = nullptr;       // N planes of B x ncol: onset posteriors rho_a(t')
+    double *extra = nullptr;      // 3*N*L edge corrections (virtual onsets, end of data)
     double *pp = nullptr;         // S: gamma[:,1] in the log domain
     int64_t *diag = nullptr;      // 8 device counters
     int64_t bytes = 0;
@@ -156,7 +160,7 @@ constexpr int psi_words_c(int N) { return (N + 1 + psi_epw_c(N) - 1) / psi_epw_c
 // steps per software-pipelined batch of the chain kernels
 template <int N> constexpr int chain_unroll() { return N <= 4 ? 4 : (N <= 8 ? 2 : 1); }
 // rows per thread of the pre-pass
-template <int N> constexpr int prepass_rows() { return N <= 4 ? 16 : (N <= 8 ? 8 : 4); }
+template <int N> constexpr int prepass_rows() { return N <= 8 ? 8 : 4; }
 
 // ring_viterbi.hip
 int ring_viterbi_launch(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st);
@@ -168,6 +172,8 @@ int ring_launch_transpose_in(RingDev *r, const double *d_y, hipStream_t st);
 int ring_launch_prepass(RingDev *r, hipStream_t st);
 int ring_launch_virtual(RingDev *r, const double *d_y, double *dst_planes, int64_t plane_stride,
                         hipStream_t st);
+int ring_bind(RingDev *r, const double *d_y, hipStream_t st);
+int ring_prepare(RingDev *r, const double *d_y, hipStream_t st);
 int ring_profile_enable(RingDev *r, int on);
 int ring_profile_read(RingDev *r, hipStream_t st, std::vector<std::string> &names,
                       std::vector<double> &ms, std::vector<int64_t> &calls);

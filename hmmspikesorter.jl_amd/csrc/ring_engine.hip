@@ -71,6 +71,7 @@ int ring_set_model(RingDev *r, const HostModel &m)
 {
     HS_CHECK(m.ring.valid && m.ring.N == r->g.N && m.ring.L == r->g.L && m.S == r->S,
              HMMSORT_EINVAL, "ring set_model: model shape changed");
+    r->bound_y = nullptr;  // ring scores depend on the model
     r->ring = m.ring;
     r->mean = m.mean;
     r->sigma = m.sigma;
@@ -90,6 +91,16 @@ int ring_set_model(RingDev *r, const HostModel &m)
         }
     }
     HS_HIP(hipMemcpy(r->d_cint, cint.data(), cint.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> msq((size_t)N * (L + 1), 0.0);  // Msq[a][kk] = sum_{k=1}^{kk} mean(a,k)^2
+    for (int a = 0; a < N; a++) {
+        double acc = 0.0;
+        for (int kk = 1; kk <= L; kk++) {
+            const double mv = m.mean[1 + (size_t)a * L + (kk - 1)];
+            acc += mv * mv;
+            msq[(size_t)a * (L + 1) + kk] = acc;
+        }
+    }
+    HS_HIP(hipMemcpy(r->d_msq, msq.data(), msq.size() * sizeof(double), hipMemcpyHostToDevice));
     std::vector<double> ctab;
     ctab.push_back(m.ring.c00);
     ctab.insert(ctab.end(), m.ring.c0.begin(), m.ring.c0.end());
@@ -117,6 +128,7 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T)
     auto A = [&](auto **p, int64_t n) { if (ok && dmalloc(p, n, &r->bytes)) ok = false; };
     A(&r->d_mean, m.S);
     A(&r->d_cint, N * (L + 1));
+    A(&r->d_msq, N * (L + 1));
     A(&r->d_ctab, 1 + 2 * N + N * N + N * L);
     A(&r->d_states, N * m.S);
     A(&r->yT, BC);
@@ -135,8 +147,10 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T)
     A(&r->part, 4 * r->nparts);
     A(&r->Zc, g.ncol);
     A(&r->B0h, g.ncol);
-    A(&r->partA, (int64_t)r->nparts * 3 * ((N * L + 255) / 256 * 256));
-    A(&r->partS, (int64_t)r->nparts * (N + 4));
+    A(&r->partA, (int64_t)(g.ncol / 64) * 2 * N * L);
+    A(&r->partS, (int64_t)(g.ncol / 64) * ((g.B + 31) / 32) * (2 * N + 3));
+    A(&r->rhoT, N * BC);
+    A(&r->extra, 3 * N * L);
     A(&r->pp, m.S);
     A(&r->diag, 8);
     if (!ok) { ring_destroy(r); return HMMSORT_ENOMEM; }
@@ -152,8 +166,9 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T)
         (void)hipMemset(r->psi, 0xFF, (int64_t)g.W * BC * 4);
         (void)hipMemset(r->xT, 0xFF, BC * 2);
         (void)hipMemset(r->Zc, 0xFF, g.ncol * 8);
-        (void)hipMemset(r->partA, 0xFF, (int64_t)r->nparts * 3 * ((N * L + 255) / 256 * 256) * 8);
-        (void)hipMemset(r->partS, 0xFF, (int64_t)r->nparts * (N + 4) * 8);
+        (void)hipMemset(r->partA, 0xFF, (int64_t)(g.ncol / 64) * 2 * N * L * 8);
+        (void)hipMemset(r->partS, 0xFF, (int64_t)(g.ncol / 64) * ((g.B + 31) / 32) * (2 * N + 3) * 8);
+        (void)hipMemset(r->rhoT, 0xFF, N * BC * 8);
     }
     if (hipMemset(r->diag, 0, 8 * sizeof(int64_t)) != hipSuccess) { ring_destroy(r); return HMMSORT_EHIP; }
     rc = ring_set_model(r, m);
@@ -165,9 +180,9 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T)
 void ring_destroy(RingDev *r)
 {
     if (!r) return;
-    void *ptrs[] = {r->d_mean, r->d_cint, r->d_ctab, r->d_states, r->yT, r->Rf, r->P, r->Q, r->A0,
+    void *ptrs[] = {r->d_mean, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->yT, r->Rf, r->P, r->Q, r->A0,
                     r->B0, r->psi, r->psiH, r->D0end, r->bstate, r->redo, r->xT, r->final_state,
-                    r->part, r->Zc, r->B0h, r->partA, r->partS, r->pp, r->diag};
+                    r->part, r->Zc, r->B0h, r->partA, r->partS, r->rhoT, r->extra, r->pp, r->diag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete r;
@@ -223,6 +238,7 @@ int ring_launch_transpose_in(RingDev *r, const double *d_y, hipStream_t st)
 // ------------------------------------------------------------------------------------------
 // pre-pass: ring scores for every onset time t' in [0, T)
 //   Rf[a][t'] = -(1/den) * sum_{k=1..kmax} (y[t'+k-1] - mean(a,k))^2 + Cint[a][kmax],
+//   (the square is expanded: sum y^2 - 2 sum y*mean + sum mean^2; fp64, error ~1e-13 absolute)
 //   kmax = min(L, T - t')   (rings that run off the end of the data are truncated: the
 //   reference's terminal conditions, viterbi.jl:90 / baumwelch.jl:80).
 // The per-sample constant A = -log2pi - log(sigma) is left out everywhere (it shifts every state
@@ -233,40 +249,56 @@ int ring_launch_transpose_in(RingDev *r, const double *d_y, hipStream_t st)
 template <int N>
 __global__ __launch_bounds__(256) void k_prepass(RingGeom g, const double *__restrict__ yT,
                                                  const double *__restrict__ mean,
-                                                 const double *__restrict__ cint, double den,
+                                                 const double *__restrict__ cint,
+                                                 const double *__restrict__ msq, double den,
                                                  double *__restrict__ Rf)
 {
-    constexpr int RS = prepass_rows<N>();
+    constexpr int RS = prepass_rows<N>();  // windows (onset rows) per thread
+    constexpr int WR = 2 * RS;             // y ring buffer: RS in use + RS fetched ahead
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int s0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RS;
     const int L = g.L, B = g.B, ncol = g.ncol;
     const int64_t T = g.T;
     const int64_t tbase = (int64_t)c * B + s0;
-    double acc[RS][N];
-#pragma unroll
-    for (int r = 0; r < RS; r++)
-#pragma unroll
-        for (int a = 0; a < N; a++) acc[r][a] = 0.0;
-    const int nj = RS + L - 1;
-    for (int j = 0; j < nj; j++) {
+    const bool cact = c < g.nch;
+    auto Y = [&](int j) -> double {  // y[tbase + j]; 0 past the end of the data (truncated rings)
+        if (!cact || tbase + j >= T) return 0.0;
         const int row = s0 + j;
-        const int64_t t = tbase + j;
-        double v = 0.0;
-        const bool in = (t < T) && (c < g.nch);
-        if (in) v = (row < B) ? yT[(int64_t)row * ncol + c] : yT[(int64_t)(row - B) * ncol + c + 1];
+        return (row < B) ? yT[(int64_t)row * ncol + c] : yT[(int64_t)(row - B) * ncol + c + 1];
+    };
+    // sum_k (y - m)^2 = sum y^2 - 2 sum y*m + sum m^2 : one fma per (window, ring, phase).
+    // Phase-outer loop: the mean of phase k is wave-uniform (N scalar loads per phase) and the RS
+    // windows slide over a register ring buffer of y (one coalesced load per phase, issued RS
+    // phases before its first use).
+    double dot[RS][N], ysq[RS], w[WR];
 #pragma unroll
-        for (int r = 0; r < RS; r++) {
-            const int k = j - r + 1;  // ring phase of sample t for the window starting at s0+r
-            if (k >= 1 && k <= L) {   // wave-uniform
+    for (int r = 0; r < RS; r++) {
+        ysq[r] = 0.0;
 #pragma unroll
-                for (int a = 0; a < N; a++) {
-                    const double d = v - mean[1 + a * L + (k - 1)];
-                    acc[r][a] += in ? d * d : 0.0;
+        for (int a = 0; a < N; a++) dot[r][a] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < WR; i++) w[i] = Y(i);
+    for (int kb = 0; kb < L; kb += WR) {
+#pragma unroll
+        for (int u = 0; u < WR; u++) {
+            const int k = kb + u + 1;
+            if (k <= L) {  // wave-uniform
+                double mv[N];
+#pragma unroll
+                for (int a = 0; a < N; a++) mv[a] = mean[1 + a * L + (k - 1)];
+#pragma unroll
+                for (int r = 0; r < RS; r++) {
+                    const double yv = w[(u + r) % WR];  // y[tbase + r + k - 1]
+                    ysq[r] += yv * yv;
+#pragma unroll
+                    for (int a = 0; a < N; a++) dot[r][a] += yv * mv[a];
                 }
+                w[u % WR] = Y(k - 1 + WR);  // slot of y[tbase + k - 1] is free now
             }
         }
     }
-    if (c >= g.nch) return;
+    if (!cact) return;
 #pragma unroll
     for (int r = 0; r < RS; r++) {
         const int64_t t0 = tbase + r;
@@ -274,9 +306,10 @@ __global__ __launch_bounds__(256) void k_prepass(RingGeom g, const double *__res
             const int64_t rem = T - t0;
             const int kmax = rem < L ? (int)rem : L;
 #pragma unroll
-            for (int a = 0; a < N; a++)
-                Rf[(int64_t)a * B * ncol + (int64_t)(s0 + r) * ncol + c] =
-                    cint[a * (L + 1) + kmax] - acc[r][a] / den;
+            for (int a = 0; a < N; a++) {
+                const double ss = (ysq[r] - 2.0 * dot[r][a]) + msq[a * (L + 1) + kmax];
+                Rf[(int64_t)a * B * ncol + (int64_t)(s0 + r) * ncol + c] = cint[a * (L + 1) + kmax] - ss / den;
+            }
         }
     }
 }
@@ -288,7 +321,7 @@ int ring_launch_prepass(RingDev *r, hipStream_t st)
         constexpr int N = decltype(n)::value;
         constexpr int RS = prepass_rows<N>();
         { PROF(r, "k_prepass", st); hipLaunchKernelGGL((k_prepass<N>), dim3(g.ncol / 64, g.B / (4 * RS)), dim3(256), 0, st, g,
-                           r->yT, r->d_mean, r->d_cint, r->den, r->Rf); }
+                           r->yT, r->d_mean, r->d_cint, r->d_msq, r->den, r->Rf); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
     });
@@ -329,6 +362,25 @@ int ring_launch_virtual(RingDev *r, const double *d_y, double *dst, int64_t plan
     { PROF(r, "k_virtual", st); hipLaunchKernelGGL(k_virtual, dim3(1), dim3(256), 0, st, r->g, d_y, r->d_mean, r->d_cint, r->den,
                        dst, plane_stride); }
     HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+// transpose + pre-pass unless d_y is the bound signal
+int ring_prepare(RingDev *r, const double *d_y, hipStream_t st)
+{
+    if (r->bound_y == d_y) return HMMSORT_OK;
+    r->bound_y = nullptr;
+    int rc;
+    if ((rc = ring_launch_transpose_in(r, d_y, st))) return rc;
+    return ring_launch_prepass(r, st);
+}
+
+int ring_bind(RingDev *r, const double *d_y, hipStream_t st)
+{
+    r->bound_y = nullptr;
+    int rc = ring_prepare(r, d_y, st);
+    if (rc) return rc;
+    r->bound_y = d_y;
     return HMMSORT_OK;
 }
 

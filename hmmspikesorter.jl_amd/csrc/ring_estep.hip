@@ -242,231 +242,248 @@ __global__ __launch_bounds__(64) void k_bwd_chain(RingGeom g, EParams<N> ep,
 }
 
 // ------------------------------------------------------------------------------------------
-// per-chain normaliser: Zc = log sum over ALL states of alpha*beta at t* = tc + L - 1
-//   silent: la0(t*) + lb0(t*);  ring state (a,k): lp_a(t') + ly_a(t'), t' = t*-k+1 in [tc, t*].
+// k_post: per-chain normaliser + posteriors.  Lane = chain.
+//   Zc = log sum over ALL states of alpha*beta at t* = tc + L - 1
+//        silent: la0(t*) + lb0(t*);  ring state (a,k): lp_a(t') + ly_a(t'), t' in [tc, t*];
+//   rho_a(t') = exp(lp_a + ly_a - Zc)  -> rhoT (transposed layout, zero where there is no onset);
+//   scalar sums: gamma_t(silent) (all t; t < T-1; times y^2), xi_a, sum_t' rho_a(t').
 // ------------------------------------------------------------------------------------------
-__global__ void k_znorm(RingGeom g, const double *__restrict__ P, const double *__restrict__ Q,
-                        const double *__restrict__ A0, const double *__restrict__ B0,
-                        double *__restrict__ Zc)
+template <int N>
+__global__ __launch_bounds__(64) void k_znorm(RingGeom g, const double *__restrict__ P,
+                                              const double *__restrict__ Q,
+                                              const double *__restrict__ A0,
+                                              const double *__restrict__ B0,
+                                              double *__restrict__ Zc)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= g.nch) return;
-    const int L = g.L, N = g.N, ncol = g.ncol;
-    const int64_t planeP = (int64_t)(g.H + g.B) * ncol, planeQ = (int64_t)(L + g.B + g.H) * ncol;
-    double m = A0[(int64_t)(1 + L - 1) * ncol + c] + B0[(int64_t)(L - 1) * ncol + c];
-    double s = 1.0;
-    for (int a = 0; a < N; a++)
-        for (int i = 0; i < L; i++) {
-            const double v = P[a * planeP + (int64_t)(g.H + i) * ncol + c] +
-                             Q[a * planeQ + (int64_t)(L + i) * ncol + c];
-            if (v > m) { s = s * exp(m - v) + 1.0; m = v; }
-            else s += exp(v - m);
-        }
-    Zc[c] = m + log(s);
+    const int H = g.H, L = g.L, ncol = g.ncol;
+    const int64_t planeP = (int64_t)(H + g.B) * ncol, planeQ = (int64_t)(L + g.B + H) * ncol;
+    const double v0 = A0[(int64_t)L * ncol + c] + B0[(int64_t)(L - 1) * ncol + c];
+    // two passes (max, then sum of exponentials): loads are independent, so they pipeline
+    double m = v0;
+#pragma unroll 4
+    for (int i = 0; i < L; i++)
+#pragma unroll
+        for (int a = 0; a < N; a++)
+            m = fmax(m, P[a * planeP + (int64_t)(H + i) * ncol + c] +
+                            Q[a * planeQ + (int64_t)(L + i) * ncol + c]);
+    double sm = exp(v0 - m);
+#pragma unroll 4
+    for (int i = 0; i < L; i++)
+#pragma unroll
+        for (int a = 0; a < N; a++)
+            sm += exp((P[a * planeP + (int64_t)(H + i) * ncol + c] +
+                       Q[a * planeQ + (int64_t)(L + i) * ncol + c]) - m);
+    Zc[c] = m + log(sm);
 }
 
-// ------------------------------------------------------------------------------------------
-// posterior statistics (baumwelch.jl:216-305 fused).  Work item = 64 chain columns x a row range;
-// tiles of TR rows: phase 1 (lane = column) turns lp+ly-Zc into rho and a per-(ring,row) bitmask
-// of the non-zero columns; phase 2 (thread = ring state (a,k)) accumulates
-//   G0 += rho, G1 += rho*y[t'+k-1], G2 += rho*y[t'+k-1]^2
-// visiting only the non-zero entries (rho underflows to exactly 0 away from spikes).
-// Pair group blockIdx.y covers ring states [256*y, 256*y+256).
-// ------------------------------------------------------------------------------------------
-struct StatsCfg {
-    int TR;          // rows per tile
-    int nitems;      // work items = (ncol/64) * rsplit
-    int rsplit;      // row ranges per column group
-    int rows_per;    // rows per work item
-    int NLpad;       // N*L rounded up to 256
-};
+// grid = (column groups, row ranges of RP rows); one wave each
+constexpr int kPostRows = 32;
 
 template <int N>
-__global__ __launch_bounds__(256) void k_stats(RingGeom g, StatsCfg cfg, JParams<N> jp,
-                                               const double *__restrict__ y,
-                                               const double *__restrict__ Rf,
-                                               const double *__restrict__ P,
-                                               const double *__restrict__ Q,
-                                               const double *__restrict__ A0,
-                                               const double *__restrict__ B0,
-                                               const double *__restrict__ Zc,
-                                               double *__restrict__ partA,
-                                               double *__restrict__ partS)
+__global__ __launch_bounds__(64) void k_post(RingGeom g, JParams<N> jp,
+                                             const double *__restrict__ yT,
+                                             const double *__restrict__ Rf,
+                                             const double *__restrict__ P,
+                                             const double *__restrict__ Q,
+                                             const double *__restrict__ A0,
+                                             const double *__restrict__ B0,
+                                             const double *__restrict__ Zc,
+                                             double *__restrict__ rhoT, double *__restrict__ partS)
 {
-    extern __shared__ double lds[];
-    const int TR = cfg.TR, L = g.L, B = g.B, H = g.H, ncol = g.ncol;
-    const int WY = TR + L - 1;                    // y window per column
-    double *rho = lds;                            // [N][TR][64]
-    double *yt = lds + (size_t)N * TR * 64;       // [64][WY]
-    unsigned long long *mask = (unsigned long long *)(yt + (size_t)64 * WY);  // [N][TR]
-    int *vlen = (int *)(mask + N * TR);           // [64] valid samples from the tile start
-    __shared__ double red[4];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int pair = blockIdx.y * 256 + tid;      // ring state handled in phase 2
-    const bool has_pair = pair < N * L;
-    const int pa = has_pair ? pair / L : 0, pk = has_pair ? pair % L + 1 : 1;
-    const bool scal = (blockIdx.y == 0);          // scalar sums are done by pair group 0 only
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * 64 + lane;
+    const int B = g.B, H = g.H, L = g.L, ncol = g.ncol;
+    const bool active = c < g.nch;
+    const int64_t tc = (int64_t)c * B;
+    const int nc = active ? (int)((g.T - tc) < B ? (g.T - tc) : B) : 0;
     const int64_t planeR = (int64_t)B * ncol, planeP = (int64_t)(H + B) * ncol,
                   planeQ = (int64_t)(L + B + H) * ncol;
-    const int64_t T = g.T;
-
-    double g0 = 0.0, g1 = 0.0, g2 = 0.0;
-    double sx[N], s_all = 0.0, s_m = 0.0, s_y2 = 0.0;
+    const double z = active ? Zc[c] : 0.0;
+    const int sbeg = blockIdx.y * kPostRows;
+    const int send = sbeg + kPostRows < B ? sbeg + kPostRows : B;
+    double sx[N], ra[N], s_all = 0.0, s_m = 0.0, s_y2 = 0.0;
 #pragma unroll
-    for (int a = 0; a < N; a++) sx[a] = 0.0;
-
-    for (int item = blockIdx.x; item < cfg.nitems; item += gridDim.x) {
-        const int c0 = (item / cfg.rsplit) * 64;
-        const int rbeg = (item % cfg.rsplit) * cfg.rows_per;
-        const int rend = rbeg + cfg.rows_per < B ? rbeg + cfg.rows_per : B;
-        const int c = c0 + lane;
-        const bool cact = c < g.nch;
-        const double z = cact ? Zc[c] : 0.0;
-        for (int r0 = rbeg; r0 < rend; r0 += TR) {
-            __syncthreads();
-            // y windows: column cl holds y[(c0+cl)*B + r0 + j], j in [0, WY)
-            for (int i = tid; i < 64 * WY; i += 256) {
-                const int cl = i / WY, j = i - cl * WY;
-                const int64_t t = (int64_t)(c0 + cl) * B + r0 + j;
-                yt[i] = (t < T) ? y[t] : 0.0;
-            }
-            if (tid < 64) {
-                const int64_t rem = T - ((int64_t)(c0 + tid) * B + r0);
-                vlen[tid] = rem < 0 ? 0 : (rem > WY ? WY : (int)rem);
-            }
-            __syncthreads();
-            // phase 1: rows r0 + wv, r0 + wv + 4, ...
-            for (int rr = wv; rr < TR; rr += 4) {
-                const int s = r0 + rr;
-                const int64_t t = (int64_t)c * B + s;
-                const bool on = cact && s < rend && t < T;
-                const int64_t offp = (int64_t)(H + s) * ncol + c, offq = (int64_t)(L + s) * ncol + c;
-                double la_prev = 0.0;
-                if (on && scal) {
-                    const double a0 = A0[(int64_t)(1 + s) * ncol + c];
-                    const double ga = exp((a0 + B0[(int64_t)s * ncol + c]) - z);  // gamma_t(silent)
-                    const double yv = yt[lane * WY + rr];
-                    s_all += ga;                       // baumwelch.jl:303 qq
-                    if (t < T - 1) s_m += ga;          // :257 bb, t = 1..T-1
-                    s_y2 += ga * (yv * yv);            // :302 with the new silent mean (= 0)
-                    la_prev = A0[(int64_t)s * ncol + c];  // la0(t-1) in this chain's frame
-                }
+    for (int a = 0; a < N; a++) { sx[a] = 0.0; ra[a] = 0.0; }
+#pragma unroll 4
+    for (int s = sbeg; s < send; s++) {
+        const int64_t off = (int64_t)s * ncol + c;
+        double rv[N];
 #pragma unroll
-                for (int a = 0; a < N; a++) {
-                    double rv = 0.0;
-                    if (on) {
-                        const double ly = Q[a * planeQ + offq];
-                        rv = exp((P[a * planeP + offp] + ly) - z);
-                        if (scal && t >= 1) {  // xi: silent at t-1 -> (a,1) at t   :240
-                            const double rf = Rf[a * planeR + (int64_t)s * ncol + c];
-                            sx[a] += exp((((la_prev + jp.c0[a]) + rf) + ly) - z);
-                        }
-                    }
-                    rho[((size_t)a * TR + rr) * 64 + lane] = rv;
-                    const unsigned long long bm = __ballot(rv != 0.0);
-                    if (lane == 0) mask[a * TR + rr] = bm;
-                }
-            }
-            __syncthreads();
-            // phase 2
-            if (has_pair) {
-                for (int rr = 0; rr < TR; rr++) {
-                    unsigned long long bm = mask[pa * TR + rr];
-                    while (bm) {
-                        const int cl = __builtin_ctzll(bm);
-                        bm &= bm - 1;
-                        const int j = rr + pk - 1;
-                        if (j < vlen[cl]) {
-                            const double rv = rho[((size_t)pa * TR + rr) * 64 + cl];
-                            const double yv = yt[cl * WY + j];
-                            g0 += rv;
-                            g1 += rv * yv;
-                            g2 += rv * (yv * yv);
-                        }
-                    }
-                }
+        for (int a = 0; a < N; a++) rv[a] = 0.0;
+        if (s < nc) {
+            const int64_t t = tc + s;
+            const int64_t offp = (int64_t)(H + s) * ncol + c, offq = (int64_t)(L + s) * ncol + c;
+            const double a0 = A0[(int64_t)(1 + s) * ncol + c];
+            const double la_prev = A0[off];                   // la0(t-1) in this chain's frame
+            const double ga = exp((a0 + B0[off]) - z);        // gamma_t(silent)
+            const double yv = yT[off];
+            s_all += ga;                                      // baumwelch.jl:303 qq
+            if (t < g.T - 1) s_m += ga;                       // :257 bb, t = 1..T-1
+            s_y2 += ga * (yv * yv);                           // :302 with the new silent mean (= 0)
+#pragma unroll
+            for (int a = 0; a < N; a++) {
+                const double ly = Q[a * planeQ + offq];
+                rv[a] = exp((P[a * planeP + offp] + ly) - z);
+                ra[a] += rv[a];
+                if (t >= 1)                                   // xi: silent(t-1) -> (a,1)(t)   :240
+                    sx[a] += exp((((la_prev + jp.c0[a]) + Rf[a * planeR + off]) + ly) - z);
             }
         }
+#pragma unroll
+        for (int a = 0; a < N; a++) rhoT[a * planeR + off] = rv[a];
     }
-    // per-block partials
-    double *pa_out = partA + (size_t)blockIdx.x * 3 * cfg.NLpad;
-    pa_out[pair] = g0;
-    pa_out[cfg.NLpad + pair] = g1;
-    pa_out[2 * cfg.NLpad + pair] = g2;
-    if (scal) {
-        double v[N + 3];
+    // wave reduction -> partS[block][2N+3] = sx | ra | s_all s_m s_y2
+    double v[2 * N + 3];
 #pragma unroll
-        for (int a = 0; a < N; a++) v[a] = sx[a];
-        v[N] = s_all; v[N + 1] = s_m; v[N + 2] = s_y2;
+    for (int a = 0; a < N; a++) { v[a] = sx[a]; v[N + a] = ra[a]; }
+    v[2 * N] = s_all; v[2 * N + 1] = s_m; v[2 * N + 2] = s_y2;
+    const size_t prow = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
 #pragma unroll
-        for (int i = 0; i < N + 3; i++) {
-            double x = v[i];
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-            __syncthreads();
-            if (lane == 0) red[wv] = x;
-            __syncthreads();
-            if (tid == 0) partS[(size_t)blockIdx.x * (N + 4) + i] = (red[0] + red[1]) + (red[2] + red[3]);
-        }
-        if (tid == 0) partS[(size_t)blockIdx.x * (N + 4) + N + 3] = 0.0;
+    for (int i = 0; i < 2 * N + 3; i++) {
+        double x = v[i];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        if (lane == 0) partS[prow * (2 * N + 3) + i] = x;
     }
 }
 
-// virtual onsets t' = -j (rings already running at the first sample) and pp = gamma[:,1]
-// (baumwelch.jl:263).  One block; appended as one more partial row.
-__global__ __launch_bounds__(256) void k_stats_virtual(RingGeom g, int NLpad, int prow,
-                                                       const double *__restrict__ y,
-                                                       const double *__restrict__ P,
-                                                       const double *__restrict__ Q,
-                                                       const double *__restrict__ A0,
-                                                       const double *__restrict__ B0,
-                                                       const double *__restrict__ Zc,
-                                                       double *__restrict__ partA,
-                                                       double *__restrict__ pp)
+// ------------------------------------------------------------------------------------------
+// k_gsum: spike-triggered sums  G1(a,k) = sum_t' rho_a(t') y[t'+k-1],  G2 likewise with y^2
+// (baumwelch.jl:270-282, :297-305).  Dense, register tiled: lane = chain, one wave = 64 chains x
+// all N rings x KB consecutive phases k; per onset row one coalesced load of y (sliding window in
+// registers) and N coalesced loads of rho feed 2*N*KB fma.  y beyond the end of the data is 0.
+// ------------------------------------------------------------------------------------------
+template <int N> constexpr int gsum_kb() { return N <= 4 ? 8 : (N <= 8 ? 4 : 2); }
+
+template <int N>
+__global__ __launch_bounds__(64) void k_gsum(RingGeom g, const double *__restrict__ yT,
+                                             const double *__restrict__ rhoT,
+                                             double *__restrict__ partG)
 {
-    const int L = g.L, N = g.N, ncol = g.ncol;
-    const int64_t planeP = (int64_t)(g.H + g.B) * ncol, planeQ = (int64_t)(L + g.B + g.H) * ncol;
-    const double z = Zc[0];
-    double *out = partA + (size_t)prow * 3 * NLpad;
-    for (int pair = threadIdx.x; pair < NLpad; pair += blockDim.x) {
-        double g0 = 0.0, g1 = 0.0, g2 = 0.0;
-        if (pair < N * L) {
-            const int a = pair / L, k = pair % L + 1;
-            for (int j = 1; j <= L - 1; j++) {
-                const int idx = -j + k - 1;
-                if (idx < 0) continue;
-                const double rv = exp((P[a * planeP + (int64_t)(g.H - j) * ncol] +
-                                       Q[a * planeQ + (int64_t)(L - j) * ncol]) - z);
-                const double yv = y[idx];
-                g0 += rv; g1 += rv * yv; g2 += rv * (yv * yv);
+    constexpr int KB = gsum_kb<N>();
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * 64 + lane;
+    const int B = g.B, L = g.L, ncol = g.ncol;
+    const int k0 = blockIdx.y * KB + 1;            // phases k0 .. k0+KB-1
+    const int64_t tb = (int64_t)c * B;
+    const int64_t planeR = (int64_t)B * ncol;
+    const bool active = c < g.nch;
+    auto Y = [&](int r) -> double {                // y[tb + r]
+        if (!active || tb + r >= g.T) return 0.0;
+        return (r < B) ? yT[(int64_t)r * ncol + c] : yT[(int64_t)(r - B) * ncol + c + 1];
+    };
+    double g1[N][KB], g2[N][KB], w[KB];
+#pragma unroll
+    for (int a = 0; a < N; a++)
+#pragma unroll
+        for (int j = 0; j < KB; j++) { g1[a][j] = 0.0; g2[a][j] = 0.0; }
+    // window for onset row s: w[(s + j) % KB] = y[tb + s + k0 - 1 + j]
+#pragma unroll
+    for (int j = 0; j < KB - 1; j++) w[j] = Y(k0 - 1 + j);
+    for (int sb = 0; sb < B; sb += KB) {
+#pragma unroll
+        for (int u = 0; u < KB; u++) {
+            const int s = sb + u;
+            w[(u + KB - 1) % KB] = Y(s + k0 + KB - 2);
+            double rv[N];
+#pragma unroll
+            for (int a = 0; a < N; a++) rv[a] = rhoT[a * planeR + (int64_t)s * ncol + c];
+#pragma unroll
+            for (int j = 0; j < KB; j++) {
+                const double yv = w[(u + j) % KB];
+                const double y2 = yv * yv;
+#pragma unroll
+                for (int a = 0; a < N; a++) {
+                    g1[a][j] += rv[a] * yv;
+                    g2[a][j] += rv[a] * y2;
+                }
             }
-            // pp for state (a,k): the onset at t' = 1-k
-            const int sp = 1 - k;
-            pp[1 + pair] = (P[a * planeP + (int64_t)(g.H + sp) * ncol] +
-                            Q[a * planeQ + (int64_t)(L + sp) * ncol]) - z;
         }
-        out[pair] = g0; out[NLpad + pair] = g1; out[2 * NLpad + pair] = g2;
+    }
+    const int NL = N * L;
+    double *out = partG + (size_t)blockIdx.x * 2 * NL;
+#pragma unroll
+    for (int a = 0; a < N; a++)
+#pragma unroll
+        for (int j = 0; j < KB; j++) {
+            double x1 = g1[a][j], x2 = g2[a][j];
+            for (int o = 32; o > 0; o >>= 1) { x1 += __shfl_xor(x1, o); x2 += __shfl_xor(x2, o); }
+            const int k = k0 + j;
+            if (lane == 0 && k <= L) {
+                out[a * L + (k - 1)] = x1;
+                out[NL + a * L + (k - 1)] = x2;
+            }
+        }
+}
+
+// virtual onsets t' = -j (rings already running at the first sample), the end-of-data correction
+// of G0 and pp = gamma[:,1] (baumwelch.jl:263).  One block.
+//   extra[0..NL)    = G0 contribution of virtual onsets  -  sum of rho over real onsets whose
+//                     phase k falls beyond the last sample (t' > T-k)
+//   extra[NL..2NL)  = G1 of virtual onsets,  extra[2NL..3NL) = G2 of virtual onsets
+__global__ __launch_bounds__(256) void k_stats_edges(RingGeom g, const double *__restrict__ y,
+                                                     const double *__restrict__ P,
+                                                     const double *__restrict__ Q,
+                                                     const double *__restrict__ A0,
+                                                     const double *__restrict__ B0,
+                                                     const double *__restrict__ Zc,
+                                                     const double *__restrict__ rhoT,
+                                                     double *__restrict__ extra,
+                                                     double *__restrict__ pp)
+{
+    const int L = g.L, N = g.N, ncol = g.ncol, NL = N * L;
+    const int64_t planeP = (int64_t)(g.H + g.B) * ncol, planeQ = (int64_t)(L + g.B + g.H) * ncol,
+                  planeR = (int64_t)g.B * ncol;
+    const double z = Zc[0];
+    for (int pair = threadIdx.x; pair < NL; pair += blockDim.x) {
+        const int a = pair / L, k = pair % L + 1;
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+        for (int j = 1; j <= L - 1; j++) {
+            const int idx = -j + k - 1;
+            if (idx < 0) continue;
+            const double rv = exp((P[a * planeP + (int64_t)(g.H - j) * ncol] +
+                                   Q[a * planeQ + (int64_t)(L - j) * ncol]) - z);
+            const double yv = y[idx];
+            g0 += rv; g1 += rv * yv; g2 += rv * (yv * yv);
+        }
+        double tail = 0.0;
+        for (int64_t t = g.T - k + 1; t < g.T; t++)
+            if (t >= 0) tail += rhoT[a * planeR + (t % g.B) * ncol + (t / g.B)];
+        extra[pair] = g0 - tail;
+        extra[NL + pair] = g1;
+        extra[2 * NL + pair] = g2;
+        const int sp = 1 - k;  // pp for state (a,k): the onset at t' = 1-k
+        pp[1 + pair] = (P[a * planeP + (int64_t)(g.H + sp) * ncol] +
+                        Q[a * planeQ + (int64_t)(L + sp) * ncol]) - z;
     }
     if (threadIdx.x == 0) pp[0] = (A0[(int64_t)1 * ncol] + B0[0]) - z;
 }
 
-// deterministic reduction of the partial rows: stats = [G0 | G1 | G2 | Xi | s_all | s_m | s_y2 | 0]
-__global__ void k_stats_reduce(int NL, int NLpad, int N, int rowsA, int rowsS,
-                               const double *__restrict__ partA, const double *__restrict__ partS,
-                               double *__restrict__ stats)
+// deterministic final assembly: stats = [G0 | G1 | G2 | Xi | s_all | s_m | s_y2 | 0];
+// one wave per output element, fixed summation order
+__global__ __launch_bounds__(64) void k_stats_final(int N, int L, int rowsG, int rowsS,
+                                                    const double *__restrict__ partG,
+                                                    const double *__restrict__ partS,
+                                                    const double *__restrict__ extra,
+                                                    double *__restrict__ stats)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = 3 * NL + N + 4;
-    if (i >= total) return;
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int NL = N * L, ws = 2 * N + 3;
     double acc = 0.0;
-    if (i < 3 * NL) {
-        const int which = i / NL, pair = i % NL;
-        for (int r = 0; r < rowsA; r++) acc += partA[(size_t)r * 3 * NLpad + which * NLpad + pair];
-    } else {
-        const int e = i - 3 * NL;
-        for (int r = 0; r < rowsS; r++) acc += partS[(size_t)r * (N + 4) + e];
+    if (i < NL) {                       // G0(a,k) = sum_t' rho_a(t') + edge corrections
+        const int a = i / L;
+        for (int r = lane; r < rowsS; r += 64) acc += partS[(size_t)r * ws + N + a];
+    } else if (i < 3 * NL) {            // G1, G2
+        const int e = i - NL;
+        for (int r = lane; r < rowsG; r += 64) acc += partG[(size_t)r * 2 * NL + e];
+    } else if (i < 3 * NL + N) {        // Xi
+        for (int r = lane; r < rowsS; r += 64) acc += partS[(size_t)r * ws + (i - 3 * NL)];
+    } else if (i < 3 * NL + N + 3) {    // s_all, s_m, s_y2
+        for (int r = lane; r < rowsS; r += 64) acc += partS[(size_t)r * ws + 2 * N + (i - 3 * NL - N)];
     }
-    stats[i] = acc;
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) stats[i] = acc + (i < 3 * NL ? extra[i] : 0.0);
 }
 
 // M-step finish (baumwelch.jl:262-307) from the (possibly all-reduced) statistics.
@@ -539,52 +556,33 @@ int ring_estep_launch(RingDev *r, const double *d_y, double *d_stats, hipStream_
     const int N = g.N, L = g.L, NL = N * L;
     int rc;
     HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
-    if ((rc = ring_launch_transpose_in(r, d_y, st))) return rc;
-    if ((rc = ring_launch_prepass(r, st))) return rc;
+    if ((rc = ring_prepare(r, d_y, st))) return rc;
     if ((rc = ring_launch_virtual(r, d_y, r->P, (int64_t)(g.H + g.B) * g.ncol, st))) return rc;
-    // stats geometry
-    StatsCfg cfg;
-    cfg.NLpad = (NL + 255) / 256 * 256;
-    const int ngroups = cfg.NLpad / 256;
-    cfg.TR = 8;
-    auto lds_bytes = [&](int TR) {
-        return (size_t)N * TR * 64 * 8 + (size_t)64 * (TR + L - 1) * 8 + (size_t)N * TR * 8 + 64 * 4;
-    };
-    while (cfg.TR > 1 && lds_bytes(cfg.TR) > 150 * 1024) cfg.TR /= 2;
-    HS_CHECK(lds_bytes(cfg.TR) <= 160 * 1024, HMMSORT_EUNSUP,
-             "ring E-step: ring length %d does not fit the statistics tile", L);
     const int colgroups = g.ncol / 64;
-    cfg.rsplit = 1;
-    while (colgroups * cfg.rsplit < 1024 && cfg.rsplit < 8 && (g.B / (cfg.rsplit * 2)) >= 64)
-        cfg.rsplit *= 2;
-    cfg.rows_per = (g.B / cfg.rsplit + cfg.TR - 1) / cfg.TR * cfg.TR;
-    cfg.nitems = colgroups * cfg.rsplit;
-    const int gx = std::min(cfg.nitems, r->nparts - 1);
     rc = dispatch_N(N, [&](auto n) {
         constexpr int NN = decltype(n)::value;
+        constexpr int KB = gsum_kb<NN>();
         EParams<NN> ep = make_eparams<NN>(r);
         JParams<NN> jp = make_jparams_e<NN>(r);
-        { PROF(r, "k_fwd_chain", st); hipLaunchKernelGGL((k_fwd_chain<NN>), dim3(g.ncol / 64), dim3(64), 0, st, g, ep, r->yT, r->Rf,
+        { PROF(r, "k_fwd_chain", st); hipLaunchKernelGGL((k_fwd_chain<NN>), dim3(colgroups), dim3(64), 0, st, g, ep, r->yT, r->Rf,
                            r->P, r->A0); }
-        { PROF(r, "k_bwd_chain", st); hipLaunchKernelGGL((k_bwd_chain<NN>), dim3(g.ncol / 64), dim3(64), 0, st, g, ep, r->yT, r->Rf,
+        { PROF(r, "k_bwd_chain", st); hipLaunchKernelGGL((k_bwd_chain<NN>), dim3(colgroups), dim3(64), 0, st, g, ep, r->yT, r->Rf,
                            r->Q, r->B0, r->B0h); }
-        { PROF(r, "k_znorm", st); hipLaunchKernelGGL(k_znorm, dim3((g.nch + 63) / 64), dim3(64), 0, st, g, r->P, r->Q, r->A0,
+        { PROF(r, "k_znorm", st); hipLaunchKernelGGL((k_znorm<NN>), dim3(colgroups), dim3(64), 0, st, g, r->P, r->Q, r->A0,
                            r->B0, r->Zc); }
-        const size_t lds = lds_bytes(cfg.TR);
-        if (lds > 64 * 1024)
-            HS_HIP(hipFuncSetAttribute((const void *)k_stats<NN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        { PROF(r, "k_stats", st); hipLaunchKernelGGL((k_stats<NN>), dim3(gx, ngroups), dim3(256), lds, st, g, cfg, jp, d_y,
-                           r->Rf, r->P, r->Q, r->A0, r->B0, r->Zc, r->partA, r->partS); }
+        { PROF(r, "k_post", st); hipLaunchKernelGGL((k_post<NN>), dim3(colgroups, (g.B + kPostRows - 1) / kPostRows), dim3(64), 0, st, g, jp, r->yT, r->Rf, r->P,
+                           r->Q, r->A0, r->B0, r->Zc, r->rhoT, r->partS); }
+        { PROF(r, "k_gsum", st); hipLaunchKernelGGL((k_gsum<NN>), dim3(colgroups, (L + KB - 1) / KB), dim3(64), 0, st, g, r->yT,
+                           r->rhoT, r->partA); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
     });
     if (rc) return rc;
-    { PROF(r, "k_stats_virtual", st); hipLaunchKernelGGL(k_stats_virtual, dim3(1), dim3(256), 0, st, g, cfg.NLpad, gx, d_y, r->P, r->Q,
-                       r->A0, r->B0, r->Zc, r->partA, r->pp); }
+    { PROF(r, "k_stats_edges", st); hipLaunchKernelGGL(k_stats_edges, dim3(1), dim3(256), 0, st, g, d_y, r->P, r->Q, r->A0, r->B0,
+                       r->Zc, r->rhoT, r->extra, r->pp); }
     const int total = 3 * NL + N + 4;
-    { PROF(r, "k_stats_reduce", st); hipLaunchKernelGGL(k_stats_reduce, dim3((total + 255) / 256), dim3(256), 0, st, NL, cfg.NLpad, N,
-                       gx + 1, gx, r->partA, r->partS, d_stats); }
+    { PROF(r, "k_stats_final", st); hipLaunchKernelGGL(k_stats_final, dim3(total), dim3(64), 0, st, N, L, colgroups,
+                       colgroups * ((g.B + kPostRows - 1) / kPostRows), r->partA, r->partS, r->extra, d_stats); }
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }

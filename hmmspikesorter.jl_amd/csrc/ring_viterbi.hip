@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void k_vit_backtrace(RingGeom g, const uint32_t
                                                       int16_t *__restrict__ xT,
                                                       int32_t *__restrict__ bstate)
 {
-    constexpr int BITS = psi_bits_c(N), EPW = psi_epw_c(N), W = psi_words_c(N), UB = 8;
+    constexpr int BITS = psi_bits_c(N), EPW = psi_epw_c(N), W = psi_words_c(N), UB = (W == 1 ? 32 : 16);
     const int c = blockIdx.x * 64 + threadIdx.x;
     const bool active = c < g.nch;
     const int B = g.B, L = g.L, ncol = g.ncol;
@@ -440,8 +440,7 @@ int ring_viterbi_launch(RingDev *r, const double *d_y, int16_t *d_x, double *d_l
     int rc;
     HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
     HS_HIP(hipMemsetAsync(r->redo, 0, sizeof(int32_t), st));
-    if ((rc = ring_launch_transpose_in(r, d_y, st))) return rc;
-    if ((rc = ring_launch_prepass(r, st))) return rc;
+    if ((rc = ring_prepare(r, d_y, st))) return rc;
     if ((rc = ring_launch_virtual(r, d_y, r->P, (int64_t)(g.H + g.B) * g.ncol, st))) return rc;
     rc = dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;

@@ -50,6 +50,13 @@ class Plan:
         check(lib().hmmsort_plan_set_model(self._h, ptr(tr), len(tr), ptr(mu), float(sigma)))
         self.lA = lA
 
+    def bind(self, d_y, stream=0):
+        """transpose + ring-score pre-pass once; following viterbi/estep calls on d_y reuse them"""
+        check(lib().hmmsort_plan_bind(self._h, _dptr(d_y), C.c_void_p(stream)))
+
+    def unbind(self):
+        check(lib().hmmsort_plan_unbind(self._h))
+
     def viterbi(self, d_y, d_x, d_ll, stream=0):
         check(lib().hmmsort_plan_viterbi(self._h, _dptr(d_y), _dptr(d_x), _dptr(d_ll),
                                          C.c_void_p(stream)))

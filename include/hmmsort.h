@@ -144,6 +144,14 @@ int hmmsort_plan_destroy(hmmsort_plan *plan);
 int hmmsort_plan_info(const hmmsort_plan *plan, int64_t *engine, int64_t *block, int64_t *halo,
                       int64_t *nchains, int64_t *workspace_bytes);
 
+/* Optional: compute the signal-dependent intermediates every ring-engine call needs (transposed
+ * copy of y and the ring scores of the current model) ONCE and let the following
+ * hmmsort_plan_viterbi / hmmsort_plan_estep calls on the same d_y reuse them.  The binding ends at
+ * hmmsort_plan_set_model, hmmsort_plan_unbind or a call with a different pointer.  The caller
+ * promises not to modify d_y while it is bound.  No-op for the generic engine. */
+int hmmsort_plan_bind(hmmsort_plan *plan, const double *d_y, void *stream);
+int hmmsort_plan_unbind(hmmsort_plan *plan);
+
 /* Viterbi decode of d_y[0..T) into d_x[0..T) (device Int16).  d_ll: one device double. */
 int hmmsort_plan_viterbi(hmmsort_plan *plan, const double *d_y, int16_t *d_x, double *d_ll,
                          void *stream);
