@@ -96,6 +96,7 @@ struct RingDev {
     int32_t *final_state = nullptr;
     double *part = nullptr;       // reduction partials
     double *Zc = nullptr;         // ncol per-chain normalisers
+    double *Zp = nullptr;         // 4 x 2 x ncol partial (max, sum) of the normaliser
     double *B0h = nullptr;        // ncol: bwd silent value one step past the chain (warm-up side)
     double *partA = nullptr;      // (ncol/64) x 2 x N*L per-wave spike-triggered sums (G1 | G2)
     double *partS = nullptr;      // (ncol/64) x (2N+3) per-wave scalar sums

@@ -146,6 +146,7 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T)
     A(&r->final_state, 8);
     A(&r->part, 4 * r->nparts);
     A(&r->Zc, g.ncol);
+    A(&r->Zp, 8 * g.ncol);
     A(&r->B0h, g.ncol);
     A(&r->partA, (int64_t)(g.ncol / 64) * 2 * N * L);
     A(&r->partS, (int64_t)(g.ncol / 64) * ((g.B + 31) / 32) * (2 * N + 3));
@@ -182,7 +183,7 @@ void ring_destroy(RingDev *r)
     if (!r) return;
     void *ptrs[] = {r->d_mean, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->yT, r->Rf, r->P, r->Q, r->A0,
                     r->B0, r->psi, r->psiH, r->D0end, r->bstate, r->redo, r->xT, r->final_state,
-                    r->part, r->Zc, r->B0h, r->partA, r->partS, r->rhoT, r->extra, r->pp, r->diag};
+                    r->part, r->Zc, r->Zp, r->B0h, r->partA, r->partS, r->rhoT, r->extra, r->pp, r->diag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete r;
@@ -290,9 +291,9 @@ __global__ __launch_bounds__(256) void k_prepass(RingGeom g, const double *__res
 #pragma unroll
                 for (int r = 0; r < RS; r++) {
                     const double yv = w[(u + r) % WR];  // y[tbase + r + k - 1]
-                    ysq[r] += yv * yv;
+                    ysq[r] = __builtin_fma(yv, yv, ysq[r]);
 #pragma unroll
-                    for (int a = 0; a < N; a++) dot[r][a] += yv * mv[a];
+                    for (int a = 0; a < N; a++) dot[r][a] = __builtin_fma(yv, mv[a], dot[r][a]);
                 }
                 w[u % WR] = Y(k - 1 + WR);  // slot of y[tbase + k - 1] is free now
             }

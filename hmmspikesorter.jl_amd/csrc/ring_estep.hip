@@ -19,6 +19,7 @@
 #include <cmath>
 #include <type_traits>
 
+#include "fastmath.h"
 #include "ring_common.h"
 
 namespace hmmsort {
@@ -32,7 +33,7 @@ struct ChainIn {
 
 // ------------------------------------------------------------------------------------------
 // forward chains (baumwelch.jl:25-51).  Same skeleton as k_vit_chain; max -> log-sum-exp.
-// The N+1 exponentials exp(value - m) are shared by all N+1 junction sums.
+// The N+1 exponentials fexp(value - m) are shared by all N+1 junction sums.
 // ------------------------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(64) void k_fwd_chain(RingGeom g, EParams<N> ep,
@@ -72,11 +73,9 @@ __global__ __launch_bounds__(64) void k_fwd_chain(RingGeom g, EParams<N> ep,
         }
     };
 
-    ChainIn<N> cur[U], nxt[U];
+    ChainIn<N> bufA[U], bufB[U];
     double la0 = 0.0;
-    load(cur, -H);
-    for (int sb = -H; sb < B; sb += U) {
-        if (sb + U < B) load(nxt, sb + U);
+    auto run = [&](ChainIn<N>(&cur)[U], int sb) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int s = sb + u;
@@ -99,22 +98,22 @@ __global__ __launch_bounds__(64) void k_fwd_chain(RingGeom g, EParams<N> ep,
                     double m = la0;
 #pragma unroll
                     for (int a = 0; a < N; a++) m = fmax(m, cur[u].X[a]);
-                    const double e0 = exp(la0 - m);
+                    const double e0 = fexp(la0 - m);
                     double e[N];
 #pragma unroll
-                    for (int a = 0; a < N; a++) e[a] = exp(cur[u].X[a] - m);
+                    for (int a = 0; a < N; a++) e[a] = fexp(cur[u].X[a] - m);
                     double ssum = e0 * ep.p00;
 #pragma unroll
-                    for (int a = 0; a < N; a++) ssum += e[a] * ep.pend[a];
+                    for (int a = 0; a < N; a++) ssum = __builtin_fma(e[a], ep.pend[a], ssum);
 #pragma unroll
                     for (int a = 0; a < N; a++) {
                         double su = e0 * ep.p0[a];
 #pragma unroll
                         for (int b = 0; b < N; b++)
-                            if (b != a) su += e[b] * ep.px[b * N + a];
-                        Pn[a] = (m + log(su)) + cur[u].R[a];
+                            if (b != a) su = __builtin_fma(e[b], ep.px[b * N + a], su);
+                        Pn[a] = (m + flog(su)) + cur[u].R[a];
                     }
-                    la0 = (m + log(ssum)) + q0;
+                    la0 = (m + flog(ssum)) + q0;
                 }
                 const int64_t offp = (int64_t)(H + s) * ncol + c;
 #pragma unroll
@@ -122,10 +121,13 @@ __global__ __launch_bounds__(64) void k_fwd_chain(RingGeom g, EParams<N> ep,
                 if (s >= -1) A0[(int64_t)(1 + s) * ncol + c] = la0;
             }
         }
-        if (sb + U < B) {
-#pragma unroll
-            for (int u = 0; u < U; u++) cur[u] = nxt[u];
-        }
+    };
+    load(bufA, -H);
+    for (int sb = -H; sb < B; sb += 2 * U) {  // ping-pong, no register copies
+        load(bufB, sb + U);
+        run(bufA, sb);
+        if (sb + 2 * U < B) load(bufA, sb + 2 * U);
+        run(bufB, sb + U);
     }
 }
 
@@ -178,12 +180,10 @@ __global__ __launch_bounds__(64) void k_bwd_chain(RingGeom g, EParams<N> ep,
         }
     };
 
-    ChainIn<N> cur[U], nxt[U];
+    ChainIn<N> bufA[U], bufB[U];
     double lb0 = 0.0;
     const int stop = B + H - 1;
-    load(cur, stop);
-    for (int sb = stop; sb >= 0; sb -= U) {
-        if (sb - U >= 0) load(nxt, sb - U);
+    auto run = [&](ChainIn<N>(&cur)[U], int sb) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int s = sb - u;
@@ -210,22 +210,22 @@ __global__ __launch_bounds__(64) void k_bwd_chain(RingGeom g, EParams<N> ep,
                         lw[a] = cur[u].R[a] + cur[u].X[a];
                         m = fmax(m, lw[a]);
                     }
-                    const double E0 = exp(v0 - m);
+                    const double E0 = fexp(v0 - m);
                     double E[N];
 #pragma unroll
-                    for (int a = 0; a < N; a++) E[a] = exp(lw[a] - m);
+                    for (int a = 0; a < N; a++) E[a] = fexp(lw[a] - m);
                     double ssum = E0 * ep.p00;
 #pragma unroll
-                    for (int a = 0; a < N; a++) ssum += E[a] * ep.p0[a];
+                    for (int a = 0; a < N; a++) ssum = __builtin_fma(E[a], ep.p0[a], ssum);
 #pragma unroll
                     for (int a = 0; a < N; a++) {
                         double su = E0 * ep.pend[a];
 #pragma unroll
                         for (int b = 0; b < N; b++)
-                            if (b != a) su += E[b] * ep.px[a * N + b];
-                        Yn[a] = m + log(su);
+                            if (b != a) su = __builtin_fma(E[b], ep.px[a * N + b], su);
+                        Yn[a] = m + flog(su);
                     }
-                    lb0 = m + log(ssum);
+                    lb0 = m + flog(ssum);
                 }
                 const int64_t offq = (int64_t)(s + 1) * ncol + c;  // onset index s-L+1 -> row s+1
 #pragma unroll
@@ -234,10 +234,13 @@ __global__ __launch_bounds__(64) void k_bwd_chain(RingGeom g, EParams<N> ep,
                 if (s == nc) B0h[c] = lb0;
             }
         }
-        if (sb - U >= 0) {
-#pragma unroll
-            for (int u = 0; u < U; u++) cur[u] = nxt[u];
-        }
+    };
+    load(bufA, stop);
+    for (int sb = stop; sb >= 0; sb -= 2 * U) {  // ping-pong, no register copies
+        load(bufB, sb - U);
+        run(bufA, sb);
+        if (sb - 2 * U >= 0) load(bufA, sb - 2 * U);
+        run(bufB, sb - U);
     }
 }
 
@@ -245,37 +248,60 @@ __global__ __launch_bounds__(64) void k_bwd_chain(RingGeom g, EParams<N> ep,
 // k_post: per-chain normaliser + posteriors.  Lane = chain.
 //   Zc = log sum over ALL states of alpha*beta at t* = tc + L - 1
 //        silent: la0(t*) + lb0(t*);  ring state (a,k): lp_a(t') + ly_a(t'), t' in [tc, t*];
-//   rho_a(t') = exp(lp_a + ly_a - Zc)  -> rhoT (transposed layout, zero where there is no onset);
+//   rho_a(t') = fexp(lp_a + ly_a - Zc)  -> rhoT (transposed layout, zero where there is no onset);
 //   scalar sums: gamma_t(silent) (all t; t < T-1; times y^2), xi_a, sum_t' rho_a(t').
 // ------------------------------------------------------------------------------------------
+constexpr int kZParts = 4;
+
+// partial log-sum-exp of the ring-state terms lp_a(t') + ly_a(t') over window rows
+// i = blockIdx.y, blockIdx.y + kZParts, ...  ->  Zp[part][0] = max, Zp[part][1] = sum exp(. - max)
 template <int N>
 __global__ __launch_bounds__(64) void k_znorm(RingGeom g, const double *__restrict__ P,
                                               const double *__restrict__ Q,
-                                              const double *__restrict__ A0,
-                                              const double *__restrict__ B0,
-                                              double *__restrict__ Zc)
+                                              double *__restrict__ Zp)
 {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= g.nch) return;
     const int H = g.H, L = g.L, ncol = g.ncol;
     const int64_t planeP = (int64_t)(H + g.B) * ncol, planeQ = (int64_t)(L + g.B + H) * ncol;
-    const double v0 = A0[(int64_t)L * ncol + c] + B0[(int64_t)(L - 1) * ncol + c];
-    // two passes (max, then sum of exponentials): loads are independent, so they pipeline
-    double m = v0;
+    double m = -INFINITY, sm = 0.0;
 #pragma unroll 4
-    for (int i = 0; i < L; i++)
+    for (int i = blockIdx.y; i < L; i += kZParts) {
+        double v[N];
 #pragma unroll
         for (int a = 0; a < N; a++)
-            m = fmax(m, P[a * planeP + (int64_t)(H + i) * ncol + c] +
-                            Q[a * planeQ + (int64_t)(L + i) * ncol + c]);
-    double sm = exp(v0 - m);
-#pragma unroll 4
-    for (int i = 0; i < L; i++)
+            v[a] = P[a * planeP + (int64_t)(H + i) * ncol + c] + Q[a * planeQ + (int64_t)(L + i) * ncol + c];
+        double mi = v[0];
 #pragma unroll
-        for (int a = 0; a < N; a++)
-            sm += exp((P[a * planeP + (int64_t)(H + i) * ncol + c] +
-                       Q[a * planeQ + (int64_t)(L + i) * ncol + c]) - m);
-    Zc[c] = m + log(sm);
+        for (int a = 1; a < N; a++) mi = fmax(mi, v[a]);
+        if (mi > m) { sm *= fexp(m - mi); m = mi; }
+#pragma unroll
+        for (int a = 0; a < N; a++) sm += fexp(v[a] - m);
+    }
+    Zp[((int64_t)blockIdx.y * 2 + 0) * ncol + c] = m;
+    Zp[((int64_t)blockIdx.y * 2 + 1) * ncol + c] = sm;
+}
+
+// Zc = log( exp(la0(t*) + lb0(t*)) + sum of the partials ),  t* = tc + L - 1
+__device__ __forceinline__ double z_combine(const RingGeom &g, const double *__restrict__ Zp,
+                                            const double *__restrict__ A0,
+                                            const double *__restrict__ B0, int c)
+{
+    const int L = g.L, ncol = g.ncol;
+    double m = A0[(int64_t)L * ncol + c] + B0[(int64_t)(L - 1) * ncol + c];
+    double pm[kZParts], ps[kZParts];
+#pragma unroll
+    for (int j = 0; j < kZParts; j++) {
+        pm[j] = Zp[((int64_t)j * 2 + 0) * ncol + c];
+        ps[j] = Zp[((int64_t)j * 2 + 1) * ncol + c];
+    }
+    const double v0 = m;
+#pragma unroll
+    for (int j = 0; j < kZParts; j++) m = fmax(m, pm[j]);
+    double sm = fexp(v0 - m);
+#pragma unroll
+    for (int j = 0; j < kZParts; j++) sm += ps[j] * fexp(pm[j] - m);
+    return m + flog(sm);
 }
 
 // grid = (column groups, row ranges of RP rows); one wave each
@@ -289,7 +315,7 @@ __global__ __launch_bounds__(64) void k_post(RingGeom g, JParams<N> jp,
                                              const double *__restrict__ Q,
                                              const double *__restrict__ A0,
                                              const double *__restrict__ B0,
-                                             const double *__restrict__ Zc,
+                                             const double *__restrict__ Zp, double *__restrict__ Zc,
                                              double *__restrict__ rhoT, double *__restrict__ partS)
 {
     const int lane = threadIdx.x;
@@ -300,7 +326,8 @@ __global__ __launch_bounds__(64) void k_post(RingGeom g, JParams<N> jp,
     const int nc = active ? (int)((g.T - tc) < B ? (g.T - tc) : B) : 0;
     const int64_t planeR = (int64_t)B * ncol, planeP = (int64_t)(H + B) * ncol,
                   planeQ = (int64_t)(L + B + H) * ncol;
-    const double z = active ? Zc[c] : 0.0;
+    const double z = active ? z_combine(g, Zp, A0, B0, c) : 0.0;
+    if (active && blockIdx.y == 0) Zc[c] = z;
     const int sbeg = blockIdx.y * kPostRows;
     const int send = sbeg + kPostRows < B ? sbeg + kPostRows : B;
     double sx[N], ra[N], s_all = 0.0, s_m = 0.0, s_y2 = 0.0;
@@ -317,7 +344,7 @@ __global__ __launch_bounds__(64) void k_post(RingGeom g, JParams<N> jp,
             const int64_t offp = (int64_t)(H + s) * ncol + c, offq = (int64_t)(L + s) * ncol + c;
             const double a0 = A0[(int64_t)(1 + s) * ncol + c];
             const double la_prev = A0[off];                   // la0(t-1) in this chain's frame
-            const double ga = exp((a0 + B0[off]) - z);        // gamma_t(silent)
+            const double ga = fexp((a0 + B0[off]) - z);        // gamma_t(silent)
             const double yv = yT[off];
             s_all += ga;                                      // baumwelch.jl:303 qq
             if (t < g.T - 1) s_m += ga;                       // :257 bb, t = 1..T-1
@@ -325,10 +352,10 @@ __global__ __launch_bounds__(64) void k_post(RingGeom g, JParams<N> jp,
 #pragma unroll
             for (int a = 0; a < N; a++) {
                 const double ly = Q[a * planeQ + offq];
-                rv[a] = exp((P[a * planeP + offp] + ly) - z);
+                rv[a] = fexp((P[a * planeP + offp] + ly) - z);
                 ra[a] += rv[a];
                 if (t >= 1)                                   // xi: silent(t-1) -> (a,1)(t)   :240
-                    sx[a] += exp((((la_prev + jp.c0[a]) + Rf[a * planeR + off]) + ly) - z);
+                    sx[a] += fexp((((la_prev + jp.c0[a]) + Rf[a * planeR + off]) + ly) - z);
             }
         }
 #pragma unroll
@@ -363,9 +390,16 @@ __global__ __launch_bounds__(64) void k_gsum(RingGeom g, const double *__restric
 {
     constexpr int KB = gsum_kb<N>();
     const int lane = threadIdx.x;
-    const int c = blockIdx.x * 64 + lane;
+    // 1-D grid, XCD-aware: the nkb waves that re-read the same 64 chain columns get consecutive
+    // slots of ONE XCD (blocks b and b+8 share an XCD), so rho/y are fetched from HBM once and
+    // served from that XCD's L2 afterwards.
+    const int nkb = (g.L + KB - 1) / KB;
+    const int grp = blockIdx.x / (8 * nkb), rem = blockIdx.x % (8 * nkb);
+    const int cgi = grp * 8 + rem % 8, kbi = rem / 8;
+    if (cgi * 64 >= g.ncol) return;
+    const int c = cgi * 64 + lane;
     const int B = g.B, L = g.L, ncol = g.ncol;
-    const int k0 = blockIdx.y * KB + 1;            // phases k0 .. k0+KB-1
+    const int k0 = kbi * KB + 1;                   // phases k0 .. k0+KB-1
     const int64_t tb = (int64_t)c * B;
     const int64_t planeR = (int64_t)B * ncol;
     const bool active = c < g.nch;
@@ -381,28 +415,41 @@ __global__ __launch_bounds__(64) void k_gsum(RingGeom g, const double *__restric
     // window for onset row s: w[(s + j) % KB] = y[tb + s + k0 - 1 + j]
 #pragma unroll
     for (int j = 0; j < KB - 1; j++) w[j] = Y(k0 - 1 + j);
-    for (int sb = 0; sb < B; sb += KB) {
+    double rvA[KB][N], yA[KB], rvB[KB][N], yB[KB];
+    auto loadb = [&](double(&rv)[KB][N], double(&yy)[KB], int sb) {
 #pragma unroll
         for (int u = 0; u < KB; u++) {
             const int s = sb + u;
-            w[(u + KB - 1) % KB] = Y(s + k0 + KB - 2);
-            double rv[N];
+            yy[u] = Y(s + k0 + KB - 2);
 #pragma unroll
-            for (int a = 0; a < N; a++) rv[a] = rhoT[a * planeR + (int64_t)s * ncol + c];
+            for (int a = 0; a < N; a++) rv[u][a] = rhoT[a * planeR + (int64_t)s * ncol + c];
+        }
+    };
+    auto run = [&](double(&rv)[KB][N], double(&yy)[KB]) {
+#pragma unroll
+        for (int u = 0; u < KB; u++) {
+            w[(u + KB - 1) % KB] = yy[u];
 #pragma unroll
             for (int j = 0; j < KB; j++) {
                 const double yv = w[(u + j) % KB];
                 const double y2 = yv * yv;
 #pragma unroll
                 for (int a = 0; a < N; a++) {
-                    g1[a][j] += rv[a] * yv;
-                    g2[a][j] += rv[a] * y2;
+                    g1[a][j] = __builtin_fma(rv[u][a], yv, g1[a][j]);
+                    g2[a][j] = __builtin_fma(rv[u][a], y2, g2[a][j]);
                 }
             }
         }
+    };
+    loadb(rvA, yA, 0);
+    for (int sb = 0; sb < B; sb += 2 * KB) {  // B is a multiple of 64 >= 2*KB
+        loadb(rvB, yB, sb + KB);
+        run(rvA, yA);
+        if (sb + 2 * KB < B) loadb(rvA, yA, sb + 2 * KB);
+        run(rvB, yB);
     }
     const int NL = N * L;
-    double *out = partG + (size_t)blockIdx.x * 2 * NL;
+    double *out = partG + (size_t)cgi * 2 * NL;
 #pragma unroll
     for (int a = 0; a < N; a++)
 #pragma unroll
@@ -442,7 +489,7 @@ __global__ __launch_bounds__(256) void k_stats_edges(RingGeom g, const double *_
         for (int j = 1; j <= L - 1; j++) {
             const int idx = -j + k - 1;
             if (idx < 0) continue;
-            const double rv = exp((P[a * planeP + (int64_t)(g.H - j) * ncol] +
+            const double rv = fexp((P[a * planeP + (int64_t)(g.H - j) * ncol] +
                                    Q[a * planeQ + (int64_t)(L - j) * ncol]) - z);
             const double yv = y[idx];
             g0 += rv; g1 += rv * yv; g2 += rv * (yv * yv);
@@ -506,7 +553,7 @@ __global__ __launch_bounds__(256) void k_mstep(int N, int L, const double *__res
     }
     for (int a = threadIdx.x; a < N; a += blockDim.x) {
         out[K * a] = 0.0;                                // row 1 stays 0 (:268 fill!, never updated)
-        out[K * N + 1 + a] = log(Xi[a]) - log(s_m);      // :264 xb[2:end]
+        out[K * N + 1 + a] = flog(Xi[a]) - flog(s_m);      // :264 xb[2:end]
     }
     for (int j = threadIdx.x; j < 1 + NL; j += blockDim.x) out[K * N + 1 + N + j] = pp[j];
     for (int o = 32; o > 0; o >>= 1) { x2 += __shfl_xor(x2, o); qq += __shfl_xor(qq, o); }
@@ -568,11 +615,11 @@ int ring_estep_launch(RingDev *r, const double *d_y, double *d_stats, hipStream_
                            r->P, r->A0); }
         { PROF(r, "k_bwd_chain", st); hipLaunchKernelGGL((k_bwd_chain<NN>), dim3(colgroups), dim3(64), 0, st, g, ep, r->yT, r->Rf,
                            r->Q, r->B0, r->B0h); }
-        { PROF(r, "k_znorm", st); hipLaunchKernelGGL((k_znorm<NN>), dim3(colgroups), dim3(64), 0, st, g, r->P, r->Q, r->A0,
-                           r->B0, r->Zc); }
+        { PROF(r, "k_znorm", st); hipLaunchKernelGGL((k_znorm<NN>), dim3(colgroups, kZParts), dim3(64), 0, st, g, r->P, r->Q,
+                           r->Zp); }
         { PROF(r, "k_post", st); hipLaunchKernelGGL((k_post<NN>), dim3(colgroups, (g.B + kPostRows - 1) / kPostRows), dim3(64), 0, st, g, jp, r->yT, r->Rf, r->P,
-                           r->Q, r->A0, r->B0, r->Zc, r->rhoT, r->partS); }
-        { PROF(r, "k_gsum", st); hipLaunchKernelGGL((k_gsum<NN>), dim3(colgroups, (L + KB - 1) / KB), dim3(64), 0, st, g, r->yT,
+                           r->Q, r->A0, r->B0, r->Zp, r->Zc, r->rhoT, r->partS); }
+        { PROF(r, "k_gsum", st); hipLaunchKernelGGL((k_gsum<NN>), dim3(((colgroups + 7) / 8) * 8 * ((L + KB - 1) / KB)), dim3(64), 0, st, g, r->yT,
                            r->rhoT, r->partA); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;

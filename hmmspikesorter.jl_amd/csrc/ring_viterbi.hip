@@ -72,12 +72,10 @@ __global__ __launch_bounds__(64) void k_vit_chain(RingGeom g, JParams<N> jp,
         }
     };
 
-    VitIn<N> cur[U], nxt[U];
+    VitIn<N> bufA[U], bufB[U];
     double D0 = 0.0;
     const int sfirst = -H;  // wave-uniform loop start (chain 0 idles through the warm-up steps)
-    load(cur, sfirst);
-    for (int sb = sfirst; sb < B; sb += U) {
-        if (sb + U < B) load(nxt, sb + U);
+    auto run = [&](VitIn<N>(&cur)[U], int sb) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int s = sb + u;
@@ -140,10 +138,15 @@ __global__ __launch_bounds__(64) void k_vit_chain(RingGeom g, JParams<N> jp,
                 if (s == nc - 1) D0end[c] = D0;
             }
         }
-        if (sb + U < B) {
-#pragma unroll
-            for (int u = 0; u < U; u++) cur[u] = nxt[u];
-        }
+    };
+    // two batches per iteration, ping-pong: a batch's inputs are fetched while the previous
+    // batch computes, with no register copies (H and B are multiples of 64, hence of 2U)
+    load(bufA, sfirst);
+    for (int sb = sfirst; sb < B; sb += 2 * U) {
+        load(bufB, sb + U);
+        run(bufA, sb);
+        if (sb + 2 * U < B) load(bufA, sb + 2 * U);
+        run(bufB, sb + U);
     }
 }
 
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(64) void k_vit_backtrace(RingGeom g, const uint32_t
                                                       int16_t *__restrict__ xT,
                                                       int32_t *__restrict__ bstate)
 {
-    constexpr int BITS = psi_bits_c(N), EPW = psi_epw_c(N), W = psi_words_c(N), UB = (W == 1 ? 32 : 16);
+    constexpr int BITS = psi_bits_c(N), EPW = psi_epw_c(N), W = psi_words_c(N), UB = 16;
     const int c = blockIdx.x * 64 + threadIdx.x;
     const bool active = c < g.nch;
     const int B = g.B, L = g.L, ncol = g.ncol;
@@ -238,39 +241,38 @@ __global__ __launch_bounds__(64) void k_vit_backtrace(RingGeom g, const uint32_t
             }
         }
     };
-    uint32_t cur[UB][W], nxt[UB][W];
+    uint32_t bufA[UB][W], bufB[UB][W];
     const int stop = B + g.H - 1;  // wave-uniform start (H <= B, so s - B < B)
-    load(cur, stop);
-    for (int sb = stop; sb >= 0; sb -= UB) {
-        if (sb - UB >= 0) load(nxt, sb - UB);
+    auto run = [&](uint32_t(&cur)[UB][W], int sb) {
 #pragma unroll
         for (int u = 0; u < UB; u++) {
             const int s = sb - u;
-            if (active && s <= se && s >= 0) {
-                const int id = (a < 0) ? 1 : 2 + a * L + (k - 1);
+            const bool live = active && s <= se && s >= 0;
+            const int id = (a < 0) ? 1 : 2 + a * L + (k - 1);
+            if (live && s <= nc) {
                 if (s < nc) xT[(int64_t)s * ncol + c] = (int16_t)id;
-                if (s == nc) bstate[c] = id;
-                if (tc + s >= 1) {
-                    if (a >= 0 && k > 1) {
-                        k--;
-                    } else {
-                        const int e = a + 1;
-                        uint32_t wsel = cur[u][0];
-#pragma unroll
-                        for (int w = 1; w < W; w++) wsel = (e / EPW == w) ? cur[u][w] : wsel;
-                        const int p = (int)((wsel >> ((e % EPW) * BITS)) & ((1u << BITS) - 1u));
-                        if (p == 0) { a = -1; k = 0; }
-                        else { a = p - 1; k = L; }
-                    }
-                }
+                else bstate[c] = id;
             }
-        }
-        if (sb - UB >= 0) {
+            // predecessor (branch-free): ring interior -> k-1; junction -> psi entry a+1
+            const int e = a + 1;
+            uint32_t wsel = cur[u][0];
 #pragma unroll
-            for (int u = 0; u < UB; u++)
-#pragma unroll
-                for (int w = 0; w < W; w++) cur[u][w] = nxt[u][w];
+            for (int w = 1; w < W; w++) wsel = (e / EPW == w) ? cur[u][w] : wsel;
+            const int p = (int)((wsel >> ((e % EPW) * BITS)) & ((1u << BITS) - 1u));
+            const bool interior = (a >= 0) && (k > 1);
+            const int na = interior ? a : p - 1;          // p == 0 -> -1 (silent)
+            const int nk = interior ? k - 1 : (p == 0 ? 0 : L);
+            const bool step = live && (tc + s >= 1);
+            a = step ? na : a;
+            k = step ? nk : k;
         }
+    };
+    load(bufA, stop);
+    for (int sb = stop; sb >= 0; sb -= 2 * UB) {
+        load(bufB, sb - UB);
+        run(bufA, sb);
+        if (sb - 2 * UB >= 0) load(bufA, sb - 2 * UB);
+        run(bufB, sb - UB);
     }
 }
 
