@@ -146,7 +146,12 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # boundary certificates: Viterbi calls fill diag[0..2], E-step calls diag[3..6]
+    plan.viterbi(dy, dx, dll, stream)
     diag = plan.diagnostics(stream)
+    plan.estep(dy, stats, stream)
+    dE = plan.diagnostics(stream)
+    diag = diag[:3] + dE[3:7]
 
     # ---- per-kernel timing (HIP events on the launch stream; separate, untimed pass) ----
     plan.profile(True)
@@ -196,7 +201,7 @@ def main():
             "detail": {"viterbi_Msamples_s": T / t_vit / 1e6, "estep_Msamples_s": T / t_est / 1e6,
                        "kernel_ms": {k: round(v, 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1])},
                        "sum_kernel_ms_per_step": step_ms_kernels,
-                       "diag": diag[:4], "workspace_GB": info["workspace_bytes"] / 1e9},
+                       "diag": diag[:7], "workspace_GB": info["workspace_bytes"] / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(H, N, K, temps, pp, sigma)

@@ -56,7 +56,7 @@ int need_device()
 
 int plan_create_engine(hmmsort_plan **out, int64_t T, const int16_t *states, int64_t N, int64_t K,
                        int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
-                       int64_t engine_req)
+                       int64_t engine_req, int64_t halo_req = -1)
 {
     HS_CHECK(out, HMMSORT_EINVAL, "plan_create: null output pointer");
     *out = nullptr;
@@ -76,7 +76,8 @@ int plan_create_engine(hmmsort_plan **out, int64_t T, const int16_t *states, int
     }
     if (engine_req != HMMSORT_ENGINE_STRICT && ring_ok) {
         p->engine = HMMSORT_ENGINE_RING;
-        rc = ring_create(&p->ring, p->model, T);
+        rc = ring_create(&p->ring, p->model, T, options().block,
+                         halo_req >= 0 ? halo_req : options().halo);
     } else {
         p->engine = HMMSORT_ENGINE_STRICT;
         rc = generic_create(&p->gen, p->model, T);
@@ -125,6 +126,8 @@ int hmmsort_set_option(const char *key, int64_t value)
     } else if (!strcmp(key, "halo")) {
         HS_CHECK(value >= 0, HMMSORT_EINVAL, "set_option: halo must be >= 0");
         o.halo = value;
+    } else if (!strcmp(key, "escalate")) {
+        o.escalate = value != 0;
     } else {
         set_error("set_option: unknown key '%s'", key);
         return HMMSORT_EINVAL;
@@ -139,6 +142,8 @@ int hmmsort_get_option(const char *key, int64_t *value)
     if (!strcmp(key, "engine")) *value = o.engine;
     else if (!strcmp(key, "block")) *value = o.block;
     else if (!strcmp(key, "halo")) *value = o.halo;
+    else if (!strcmp(key, "escalate")) *value = o.escalate;
+    else if (!strcmp(key, "last_escalations")) *value = o.last_escalations;
     else {
         set_error("get_option: unknown key '%s'", key);
         return HMMSORT_EINVAL;
@@ -294,23 +299,50 @@ int hmmsort_plan_profile_read(hmmsort_plan *p, void *stream, char *names, int64_
 
 // ---- host-buffer entry points --------------------------------------------------------------
 
+// Ring-engine calls certify their own chain boundaries on device; when a check fails the
+// host-buffer entry points retry with a doubled warm-up (up to the chain length of a single
+// chain) and finally with the strict engine.
+static int64_t next_halo(const hmmsort_plan *p)
+{
+    int64_t b = 0, h = 0, n = 0;
+    ring_geometry(p->ring, &b, &h, &n);
+    return h * 2;
+}
+
 int hmmsort_viterbi(const double *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
                     int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
                     int16_t *x_out, double *ll_out)
 {
     HS_CHECK(y && x_out && ll_out, HMMSORT_EINVAL, "viterbi: null argument");
     HS_CHECK(T >= 1, HMMSORT_EINVAL, "viterbi: empty signal (T = %lld)", (long long)T);
-    PlanGuard pg;
-    int rc = hmmsort_plan_create(&pg.p, T, states, N, K, S, tr, R, mu, sigma);
-    if (rc) return rc;
     DevBuf dy, dx, dll;
+    int rc;
+    if ((rc = need_device())) return rc;
     if ((rc = dy.alloc(T * sizeof(double))) || (rc = dx.alloc(T * sizeof(int16_t))) ||
         (rc = dll.alloc(sizeof(double))))
         return rc;
     HS_HIP(hipMemcpy(dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
-    rc = hmmsort_plan_viterbi(pg.p, dy.as<double>(), dx.as<int16_t>(), dll.as<double>(), nullptr);
-    if (rc) return rc;
-    HS_HIP(hipDeviceSynchronize());
+    options().last_escalations = 0;
+    int64_t halo = -1, engine = options().engine;
+    for (int attempt = 0;; attempt++) {
+        PlanGuard pg;
+        rc = plan_create_engine(&pg.p, T, states, N, K, S, tr, R, mu, sigma, engine, halo);
+        if (rc) return rc;
+        rc = hmmsort_plan_viterbi(pg.p, dy.as<double>(), dx.as<int16_t>(), dll.as<double>(), nullptr);
+        if (rc) return rc;
+        HS_HIP(hipDeviceSynchronize());
+        if (!pg.p->ring) break;
+        int64_t diag[8];
+        if ((rc = ring_diagnostics(pg.p->ring, nullptr, diag))) return rc;
+        if (diag[0] == 0 || !options().escalate) break;
+        options().last_escalations = attempt + 1;
+        halo = next_halo(pg.p);
+        if (attempt >= 3 || halo > T) {
+            HS_CHECK(options().engine != HMMSORT_ENGINE_RING, HMMSORT_ENOCONV,
+                     "viterbi: %lld chain boundaries still fail the warm-up check", (long long)diag[0]);
+            engine = HMMSORT_ENGINE_STRICT;
+        }
+    }
     HS_HIP(hipMemcpy(x_out, dx.p, T * sizeof(int16_t), hipMemcpyDeviceToHost));
     HS_HIP(hipMemcpy(ll_out, dll.p, sizeof(double), hipMemcpyDeviceToHost));
     return HMMSORT_OK;
@@ -405,13 +437,19 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
 {
     HS_CHECK(y && mu_inout && sigma_out && lp_out, HMMSORT_EINVAL, "em_step: null argument");
     HS_CHECK(T >= 2, HMMSORT_EINVAL, "em_step: need T >= 2");
-    PlanGuard pg;
-    int rc = hmmsort_plan_create(&pg.p, T, states, N, K, S, tr, R, mu_inout, sigma);
-    if (rc) return rc;
+    int rc;
+    if ((rc = need_device())) return rc;
     DevBuf dy;
     if ((rc = dy.alloc(T * sizeof(double)))) return rc;
     HS_HIP(hipMemcpy(dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
-    if (pg.p->ring) {
+    options().last_escalations = 0;
+    PlanGuard pg;
+    int64_t halo = -1, engine = options().engine;
+    for (int attempt = 0;; attempt++) {
+        if (pg.p) { hmmsort_plan_destroy(pg.p); pg.p = nullptr; }
+        rc = plan_create_engine(&pg.p, T, states, N, K, S, tr, R, mu_inout, sigma, engine, halo);
+        if (rc) return rc;
+        if (!pg.p->ring) break;
         const int64_t nlp = N;
         DevBuf dstats, dout;
         if ((rc = dstats.alloc(ring_stats_len(pg.p->ring) * sizeof(double))) ||
@@ -420,8 +458,19 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
         if ((rc = ring_estep(pg.p->ring, dy.as<double>(), dstats.as<double>(), nullptr))) return rc;
         if ((rc = ring_mstep(pg.p->ring, dstats.as<double>(), dout.as<double>(), nullptr))) return rc;
         HS_HIP(hipDeviceSynchronize());
-        return unpack_mstep(dout.as<double>(), K, N, S, nlp, mu_inout, sigma_out, lp_out, lp_cap,
-                            n_lp_out, pp_out);
+        int64_t diag[8];
+        if ((rc = ring_diagnostics(pg.p->ring, nullptr, diag))) return rc;
+        if ((diag[3] == 0 && diag[5] == 0) || !options().escalate)
+            return unpack_mstep(dout.as<double>(), K, N, S, nlp, mu_inout, sigma_out, lp_out, lp_cap,
+                                n_lp_out, pp_out);
+        options().last_escalations = attempt + 1;
+        halo = next_halo(pg.p);
+        if (attempt >= 3 || halo > T) {
+            HS_CHECK(options().engine != HMMSORT_ENGINE_RING, HMMSORT_ENOCONV,
+                     "em_step: %lld chain boundaries still fail the warm-up check",
+                     (long long)(diag[3] + diag[5]));
+            engine = HMMSORT_ENGINE_STRICT;
+        }
     }
     // generic engine: forward -> backward -> update with materialised alpha/beta, all on device
     const int64_t nlp = generic_n_lp(pg.p->gen);

@@ -37,6 +37,8 @@ struct Options {
     int64_t engine = HMMSORT_ENGINE_AUTO;
     int64_t block = 0;
     int64_t halo = 0;
+    int64_t escalate = 1;          // host-buffer entry points retry with a doubled warm-up
+    int64_t last_escalations = 0;  // read-only: retries of the last host-buffer call
 };
 Options &options();
 
@@ -92,7 +94,7 @@ int generic_update(GenericDev *g, const double *d_alpha, const double *d_beta, c
 int64_t generic_n_lp(const GenericDev *g);
 
 // ring (time-parallel) engine
-int ring_create(RingDev **r, const HostModel &m, int64_t T);
+int ring_create(RingDev **r, const HostModel &m, int64_t T, int64_t block_req, int64_t halo_req);
 int ring_set_model(RingDev *r, const HostModel &m);
 void ring_destroy(RingDev *r);
 int64_t ring_workspace_bytes(const RingDev *r);

@@ -90,6 +90,7 @@ struct RingDev {
     uint32_t *psi = nullptr;      // W planes of B x ncol
     uint32_t *psiH = nullptr;     // W planes of Lc x ncol
     double *D0end = nullptr;      // ncol
+    double *D0pre = nullptr;      // ncol: delta(silent) at tc-1 in chain c's warm-up frame
     int32_t *bstate = nullptr;    // ncol
     int32_t *redo = nullptr;      // list of chains to re-walk (capacity ncol)
     int16_t *xT = nullptr;        // B x ncol

@@ -24,16 +24,17 @@ bool ring_supported(const HostModel &m, int64_t T, std::string *why)
     return true;
 }
 
-static int make_geometry(RingGeom &g, int64_t T, int N, int L)
+static int make_geometry(RingGeom &g, int64_t T, int N, int L, int64_t block_req, int64_t halo_req)
 {
-    const Options &o = options();
     g.T = T; g.N = N; g.L = L;
-    // warm-up: >= 4 ring lengths and >= 256 samples (see DESIGN.md "halo")
-    int64_t H = o.halo > 0 ? o.halo : std::max<int64_t>(256, 4 * (int64_t)L);
-    H = round_up(std::max<int64_t>(H, L + 1), 64);
-    // chain length: enough chains to fill 1024 SIMDs x 64 lanes, but never shorter than the halo
-    int64_t B = o.block > 0 ? o.block : std::max<int64_t>(H, (T + 65535) / 65536);
-    B = round_up(std::max<int64_t>(B, std::max<int64_t>(H, L)), 64);
+    // warm-up: four ring lengths, at least 256 samples.  Whether a warm-up was long enough is
+    // CHECKED on device after every call (k_halo_check, k_fb_check); the host-buffer entry points
+    // double it and retry when a check fails (DESIGN.md "warm-up").
+    int64_t H = halo_req > 0 ? halo_req : std::max<int64_t>(256, 4 * (int64_t)L);
+    H = round_up(std::max<int64_t>(H, L + 40), 64);  // the boundary checks need L+8 settled steps
+    // chain length: twice the warm-up, or longer when the signal alone fills 1024 SIMDs x 64 lanes
+    int64_t B = block_req > 0 ? block_req : std::max<int64_t>(H, (T + 65535) / 65536);
+    B = round_up(std::max<int64_t>(B, std::max<int64_t>(std::max<int64_t>(H, L + 16), 128)), 64);
     if (B > T) B = round_up(T, 64);
     if (H > B) H = B;
     // every chain must own >= L samples (the per-chain normaliser needs a full ring window)
@@ -113,12 +114,12 @@ int ring_set_model(RingDev *r, const HostModel &m)
     return HMMSORT_OK;
 }
 
-int ring_create(RingDev **out, const HostModel &m, int64_t T)
+int ring_create(RingDev **out, const HostModel &m, int64_t T, int64_t block_req, int64_t halo_req)
 {
     std::string why;
     HS_CHECK(ring_supported(m, T, &why), HMMSORT_EUNSUP, "ring engine: %s", why.c_str());
     RingDev *r = new RingDev();
-    int rc = make_geometry(r->g, T, m.ring.N, m.ring.L);
+    int rc = make_geometry(r->g, T, m.ring.N, m.ring.L, block_req, halo_req);
     if (rc) { delete r; return rc; }
     r->S = m.S; r->K = m.K;
     const RingGeom &g = r->g;
@@ -140,6 +141,7 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T)
     A(&r->psi, (int64_t)g.W * BC);
     A(&r->psiH, (int64_t)g.W * g.Lc * g.ncol);
     A(&r->D0end, g.ncol);
+    A(&r->D0pre, g.ncol);
     A(&r->bstate, g.ncol);
     A(&r->redo, g.ncol + 8);
     A(&r->xT, BC);
@@ -182,7 +184,7 @@ void ring_destroy(RingDev *r)
 {
     if (!r) return;
     void *ptrs[] = {r->d_mean, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->yT, r->Rf, r->P, r->Q, r->A0,
-                    r->B0, r->psi, r->psiH, r->D0end, r->bstate, r->redo, r->xT, r->final_state,
+                    r->B0, r->psi, r->psiH, r->D0end, r->D0pre, r->bstate, r->redo, r->xT, r->final_state,
                     r->part, r->Zc, r->Zp, r->B0h, r->partA, r->partS, r->rhoT, r->extra, r->pp, r->diag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

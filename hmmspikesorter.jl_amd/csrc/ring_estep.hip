@@ -464,6 +464,106 @@ __global__ __launch_bounds__(64) void k_gsum(RingGeom g, const double *__restric
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// Boundary certificate of the warm-ups (diag[3..6]).  Lane = boundary between chains c-1 and c.
+// Forward: the state chain c reached at the end of its warm-up (la0 at tc-1 and the L onsets
+// still inside their rings) against what chain c-1 computed for the same quantities; backward:
+// the state chain c-1 reached at tc coming down from its warm-up (lb0 at tc and the ring-end
+// betas Y_a(tc..tc+L-2)) against chain c's own.  Both pairs may differ by a frame constant D,
+// taken at the entry with the largest posterior weight; the error is the posterior-weighted
+// relative mismatch  sum_e w_e * |exp((x_e - x'_e) - D) - 1|  (entries nobody can reach have
+// weight ~0 and do not count).
+// ------------------------------------------------------------------------------------------
+constexpr int kChkParts = 8;
+
+// block = 64 boundaries x kChkParts entry subsets (512 threads); partial results meet in LDS
+template <int N>
+__global__ __launch_bounds__(64 * kChkParts) void k_fb_check(RingGeom g, double tol,
+                                                            const double *__restrict__ P,
+                                                            const double *__restrict__ Q,
+                                                            const double *__restrict__ A0,
+                                                            const double *__restrict__ B0,
+                                                            const double *__restrict__ B0h,
+                                                            const double *__restrict__ Zc,
+                                                            const double *__restrict__ rhoT,
+                                                            int64_t *__restrict__ diag)
+{
+    __shared__ double shw[kChkParts][64], shd[kChkParts][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;  // boundary at tc = c*B, c >= 1
+    const bool on = c >= 1 && c < g.nch;
+    const int B = g.B, H = g.H, L = g.L, ncol = g.ncol;
+    const int64_t planeR = (int64_t)B * ncol, planeP = (int64_t)(H + B) * ncol,
+                  planeQ = (int64_t)(L + B + H) * ncol;
+    const int cp = c - 1;
+    for (int dir = 0; dir < 2; dir++) {
+        // entry e of ring a: forward j = e+1 (onset tc-j), backward i = e (ring-end beta at tc+i)
+        const int ne = dir == 0 ? L : L - 1;
+        auto wofs = [&](int a, int e) {   // posterior weight of the entry (rho of chain c-1)
+            const int row = dir == 0 ? B - (e + 1) : B + e - L + 1;
+            return a * planeR + (int64_t)row * ncol + cp;
+        };
+        auto diff = [&](int a, int e) {   // this chain's warm-up value minus the neighbour's
+            double hv, mv;
+            if (dir == 0) {
+                hv = P[a * planeP + (int64_t)(H - (e + 1)) * ncol + c];
+                mv = P[a * planeP + (int64_t)(H + B - (e + 1)) * ncol + cp];
+            } else {
+                hv = Q[a * planeQ + (int64_t)(B + e + 1) * ncol + cp];
+                mv = Q[a * planeQ + (int64_t)(e + 1) * ncol + c];
+            }
+            return (hv == mv) ? 0.0 : hv - mv;   // also covers -inf vs -inf
+        };
+        double w0 = 0.0, d0 = 0.0;
+        if (on) {
+            if (dir == 0) {
+                const double m0 = A0[(int64_t)B * ncol + cp];
+                d0 = A0[c] - m0;
+                w0 = fexp((m0 + B0[(int64_t)(B - 1) * ncol + cp]) - Zc[cp]);
+            } else {
+                const double m0 = B0[c];
+                d0 = B0h[cp] - m0;
+                w0 = fexp((A0[(int64_t)1 * ncol + c] + m0) - Zc[c]);
+            }
+        }
+        // phase 1: entry with the largest weight -> frame constant D
+        double wb = part == 0 ? w0 : -1.0, db = d0;
+        if (on)
+            for (int a = 0; a < N; a++)
+                for (int e = part; e < ne; e += kChkParts) {
+                    const double w = rhoT[wofs(a, e)];
+                    if (w > wb) { wb = w; db = diff(a, e); }
+                }
+        shw[part][lane] = wb; shd[part][lane] = db;
+        __syncthreads();
+        double D = shd[0][lane], wbest = shw[0][lane];
+#pragma unroll
+        for (int q = 1; q < kChkParts; q++)
+            if (shw[q][lane] > wbest) { wbest = shw[q][lane]; D = shd[q][lane]; }
+        __syncthreads();
+        // phase 2: posterior-weighted relative mismatch
+        double err = part == 0 ? w0 * fabs(fexp(fmin(d0 - D, 700.0)) - 1.0) : 0.0;
+        if (on)
+            for (int a = 0; a < N; a++)
+#pragma unroll 2
+                for (int e = part; e < ne; e += kChkParts) {
+                    const double w = rhoT[wofs(a, e)];
+                    if (w > 0.0) err += w * fabs(fexp(fmin(diff(a, e) - D, 700.0)) - 1.0);
+                }
+        shw[part][lane] = err;
+        __syncthreads();
+        if (part == 0 && on) {
+            double tot = 0.0;
+#pragma unroll
+            for (int q = 0; q < kChkParts; q++) tot += shw[q][lane];
+            if (!(tot <= tol)) atomicAdd((unsigned long long *)&diag[3 + 2 * dir], 1ull);
+            if (tot == tot)
+                atomicMax((unsigned long long *)&diag[4 + 2 * dir], (unsigned long long)__double_as_longlong(tot));
+        }
+        __syncthreads();
+    }
+}
+
 // virtual onsets t' = -j (rings already running at the first sample), the end-of-data correction
 // of G0 and pp = gamma[:,1] (baumwelch.jl:263).  One block.
 //   extra[0..NL)    = G0 contribution of virtual onsets  -  sum of rho over real onsets whose
@@ -621,6 +721,8 @@ int ring_estep_launch(RingDev *r, const double *d_y, double *d_stats, hipStream_
                            r->Q, r->A0, r->B0, r->Zp, r->Zc, r->rhoT, r->partS); }
         { PROF(r, "k_gsum", st); hipLaunchKernelGGL((k_gsum<NN>), dim3(((colgroups + 7) / 8) * 8 * ((L + KB - 1) / KB)), dim3(64), 0, st, g, r->yT,
                            r->rhoT, r->partA); }
+        { PROF(r, "k_fb_check", st); hipLaunchKernelGGL((k_fb_check<NN>), dim3(colgroups), dim3(64 * kChkParts), 0, st, g, 1e-9, r->P, r->Q,
+                           r->A0, r->B0, r->B0h, r->Zc, r->rhoT, r->diag); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
     });

@@ -76,7 +76,11 @@ class Plan:
     def diagnostics(self, stream=0):
         d = (C.c_int64 * 8)()
         check(lib().hmmsort_plan_diagnostics(self._h, C.c_void_p(stream), d))
-        return list(d)
+        out = list(d)
+        import struct
+        for i in (2, 4, 6):  # largest boundary errors travel as double bit patterns
+            out[i] = struct.unpack("<d", struct.pack("<q", out[i]))[0]
+        return out
 
     def profile(self, enable=True):
         check(lib().hmmsort_plan_profile(self._h, int(bool(enable))))

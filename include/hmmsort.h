@@ -165,9 +165,13 @@ int64_t hmmsort_plan_stats_len(const hmmsort_plan *plan);
  * [mu (K*N) | sigma (1) | lp_new (N) | pp (S)] = K*N + 1 + N + S doubles. */
 int hmmsort_plan_mstep(hmmsort_plan *plan, const double *d_stats, double *d_out, void *stream);
 /* diagnostics of the last ring-engine call on this plan (synchronises the stream):
- * diag[0] = number of chain boundaries whose warm-up check failed (Viterbi),
- * diag[1] = number of backtrace stitch repairs, diag[2] = halo escalations,
- * diag[3] = forward-backward boundary failures. */
+ * diag[0] = chain boundaries whose Viterbi warm-up missed the certificate (the warm-up's boundary
+ *           scores must equal the previous chain's up to one constant, tolerance 1e-6),
+ * diag[1] = backtrace stitch repairs, diag[2] = largest spread seen by that certificate (bit
+ *           pattern of a double), diag[3] / diag[5] = chain boundaries whose forward / backward warm-up
+ *           missed the posterior-weighted tolerance 1e-9, diag[4] / diag[6] = the largest such
+ *           error (IEEE-754 bit pattern of a double).  Viterbi calls fill [0..1], E-step calls
+ *           [3..6]. */
 int hmmsort_plan_diagnostics(hmmsort_plan *plan, void *stream, int64_t diag[8]);
 
 /* Per-kernel timing of the ring engine with HIP events recorded on the caller's stream (used by

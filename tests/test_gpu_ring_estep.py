@@ -127,3 +127,31 @@ def test_em_driver_recovers_templates(O, H):
     for i in range(2):
         assert np.sum((mu[:, i] - temps[:, i]) ** 2) / np.sum(temps[:, i] ** 2) < 0.01
     assert abs(sig - 0.3) < 0.01
+
+
+def test_busy_signal_certificate_and_escalation(O, H):
+    # nearly always-busy chain: the posterior-weighted boundary certificate (diag[3..6]) must
+    # either pass with tiny errors or make the host-buffer entry point retry; either way the
+    # returned step matches the oracle
+    K, N, T = 60, 4, 40_000
+    temps = four_templates(H, K)
+    pp = [0.03, 0.02, 0.025, 0.02]
+    y = H.create_signal(T, 0.3, pp, temps, seed=21)
+    sm = H.StateMatrix.create(N, K, np.log(pp), False)
+    mu = np.asfortranarray(temps * 0.9)
+    mu[0, :] = 0
+    H.set_option("block", 128)
+    H.set_option("halo", 128)
+    _compare_step(O, H, y, sm, mu, 0.35, rtol=1e-7)
+    esc = H.get_option("last_escalations")
+    import torch
+    plan = H.Plan(T, sm, mu, 0.35)
+    st = torch.cuda.current_stream().cuda_stream
+    dy = torch.from_numpy(y).cuda()
+    stats = torch.zeros(plan.stats_len(), dtype=torch.float64, device="cuda")
+    plan.estep(dy, stats, st)
+    diag = plan.diagnostics(st)
+    plan.close()
+    print("busy signal: escalations", esc, "diag", diag)
+    assert (diag[3] + diag[5] > 0) == (esc > 0) or esc == 0
+    assert max(diag[4], diag[6]) >= 0.0

@@ -107,18 +107,33 @@ def test_model_quirks(O, H):
         assert np.array_equal(x, xo) and abs(ll - llo) <= 1e-9 * abs(llo) and diag[0] == 0
 
 
-def test_too_short_warmup_is_detected(H):
-    # a warm-up of about one ring length cannot forget its start; the boundary check must notice
-    K, N, T = 60, 4, 200_000
+def _busy_signal(H, T, seed):
+    """Four neurons firing so often that the chain is almost never silent: the regime in which a
+    short warm-up cannot forget its start."""
+    K, N = 60, 4
     temps = four_templates(H, K)
-    pp = [0.003, 0.001, 0.002, 0.0015]
-    y = H.create_signal(T, 0.3, pp, temps, seed=5)
+    pp = [0.03, 0.02, 0.025, 0.02]
+    y = H.create_signal(T, 0.3, pp, temps, seed=seed)
     sm = H.StateMatrix.create(N, K, np.log(pp), False)
-    H.set_option("block", 64)
-    H.set_option("halo", 64)
-    x, ll, diag, info = _decode_with_plan(H, y, sm, temps, 0.3)
-    assert info["halo"] == 64
-    assert diag[0] + diag[1] > 0
+    return y, sm, temps
+
+
+def test_too_short_warmup_is_detected_and_escalated(O, H):
+    y, sm, temps = _busy_signal(H, 150_000, 5)
+    H.set_option("block", 128)
+    H.set_option("halo", 128)
+    x, ll, diag, info = _decode_with_plan(H, y, sm, temps, 0.3)   # plan API: no retry, only flags
+    xo, llo = O.viterbi(y, to_oracle_sm(O, sm), temps, 0.3)
+    assert info["halo"] == 128
+    nbad = int(np.count_nonzero(x != xo))
+    # whenever the short warm-up changed the path, the boundary check must have fired
+    assert nbad == 0 or diag[0] + diag[1] > 0, (nbad, diag)
+    # host-buffer entry point: same options, but it retries with a doubled warm-up until the
+    # checks pass -> the oracle's path
+    x2, ll2 = H.viterbi(y, sm, temps, 0.3)
+    assert np.array_equal(x2, xo), (int(np.count_nonzero(x2 != xo)), H.get_option("last_escalations"))
+    if diag[0] > 0:
+        assert H.get_option("last_escalations") >= 1
 
 
 def test_ring_matches_strict_engine_on_gpu(H):
