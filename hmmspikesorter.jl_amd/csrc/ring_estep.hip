@@ -49,26 +49,28 @@ __global__ __launch_bounds__(64) void k_fwd_chain(RingGeom g, EParams<N> ep,
     const int nc = active ? (int)((g.T - tc) < B ? (g.T - tc) : B) : 0;
     const int s0 = (c == 0) ? 0 : -H;
     const int64_t planeR = (int64_t)B * ncol, planeP = (int64_t)(H + B) * ncol;
-    const int cin = c > 0 ? c - 1 : 0;
 
-    auto load = [&](ChainIn<N>(&d)[U], int sb) {
+    auto load = [&](ChainIn<N>(&d)[U], int sb) {  // unconditional loads, see k_vit_chain
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int s = sb + u;
             const bool live = active && s >= s0 && s < nc;
-            d[u].y = 0.0;
+            const int sc = live ? s : 0;
+            const int cc = active ? c : 0;
+            const int64_t off = (sc >= 0) ? (int64_t)sc * ncol + cc : (int64_t)(B + sc) * ncol + (cc > 0 ? cc - 1 : 0);
+            const bool hasx = live && (s - L >= -H);
+            const int64_t offp = (int64_t)(hasx ? H + s - L : H) * ncol + cc;
+            const double yv = yT[off];
+            double rv[N], xv[N];
 #pragma unroll
-            for (int a = 0; a < N; a++) { d[u].R[a] = 0.0; d[u].X[a] = -INFINITY; }
-            if (live) {
-                const int64_t off = (s >= 0) ? (int64_t)s * ncol + c : (int64_t)(B + s) * ncol + cin;
-                d[u].y = yT[off];
+            for (int a = 0; a < N; a++) rv[a] = Rf[a * planeR + off];
 #pragma unroll
-                for (int a = 0; a < N; a++) d[u].R[a] = Rf[a * planeR + off];
-                if (s - L >= -H) {
-                    const int64_t offp = (int64_t)(H + s - L) * ncol + c;
+            for (int a = 0; a < N; a++) xv[a] = P[a * planeP + offp];
+            d[u].y = live ? yv : 0.0;
 #pragma unroll
-                    for (int a = 0; a < N; a++) d[u].X[a] = P[a * planeP + offp];
-                }
+            for (int a = 0; a < N; a++) {
+                d[u].R[a] = live ? rv[a] : 0.0;
+                d[u].X[a] = hasx ? xv[a] : -INFINITY;
             }
         }
     };
@@ -98,22 +100,28 @@ __global__ __launch_bounds__(64) void k_fwd_chain(RingGeom g, EParams<N> ep,
                     double m = la0;
 #pragma unroll
                     for (int a = 0; a < N; a++) m = fmax(m, cur[u].X[a]);
-                    const double e0 = fexp(la0 - m);
-                    double e[N];
+                    double ev[N + 1];  // exp(value - m), shared by all junction sums
+                    ev[N] = la0 - m;
 #pragma unroll
-                    for (int a = 0; a < N; a++) e[a] = fexp(cur[u].X[a] - m);
-                    double ssum = e0 * ep.p00;
+                    for (int a = 0; a < N; a++) ev[a] = cur[u].X[a] - m;
+                    fexp_n<N + 1>(ev);
+                    const double e0 = ev[N];
+                    double sv[N + 1];  // the N+1 junction sums
+                    sv[N] = e0 * ep.p00;
 #pragma unroll
-                    for (int a = 0; a < N; a++) ssum = __builtin_fma(e[a], ep.pend[a], ssum);
+                    for (int a = 0; a < N; a++) sv[N] = __builtin_fma(ev[a], ep.pend[a], sv[N]);
 #pragma unroll
                     for (int a = 0; a < N; a++) {
                         double su = e0 * ep.p0[a];
 #pragma unroll
                         for (int b = 0; b < N; b++)
-                            if (b != a) su = __builtin_fma(e[b], ep.px[b * N + a], su);
-                        Pn[a] = (m + flog(su)) + cur[u].R[a];
+                            if (b != a) su = __builtin_fma(ev[b], ep.px[b * N + a], su);
+                        sv[a] = su;
                     }
-                    la0 = (m + flog(ssum)) + q0;
+                    flog_n<N + 1>(sv);
+#pragma unroll
+                    for (int a = 0; a < N; a++) Pn[a] = (m + sv[a]) + cur[u].R[a];
+                    la0 = (m + sv[N]) + q0;
                 }
                 const int64_t offp = (int64_t)(H + s) * ncol + c;
 #pragma unroll
@@ -157,25 +165,27 @@ __global__ __launch_bounds__(64) void k_bwd_chain(RingGeom g, EParams<N> ep,
     const int64_t planeR = (int64_t)B * ncol, planeQ = (int64_t)(L + B + H) * ncol;
 
     // inputs of step s (computing time t = tc+s from t+1): y, Rf and ly at time t+1
-    auto load = [&](ChainIn<N>(&d)[U], int sb) {
+    auto load = [&](ChainIn<N>(&d)[U], int sb) {  // unconditional loads, see k_vit_chain
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int s = sb - u;
             const bool live = active && s < se && s >= 0;
-            d[u].y = 0.0;
+            const int s1 = live ? s + 1 : 0;
+            const int cc = active ? c : 0;
+            const int64_t off = (s1 < B) ? (int64_t)s1 * ncol + cc : (int64_t)(s1 - B) * ncol + cc + 1;
+            const bool hasq = live && (s + L <= se);  // the ring started at t+1 ends inside the range
+            const int64_t offq = (int64_t)(hasq ? L + s1 : L) * ncol + cc;
+            const double yv = yT[off];
+            double rv[N], xv[N];
 #pragma unroll
-            for (int a = 0; a < N; a++) { d[u].R[a] = 0.0; d[u].X[a] = 0.0; }
-            if (live) {
-                const int s1 = s + 1;
-                const int64_t off = (s1 < B) ? (int64_t)s1 * ncol + c : (int64_t)(s1 - B) * ncol + c + 1;
-                d[u].y = yT[off];
+            for (int a = 0; a < N; a++) rv[a] = Rf[a * planeR + off];
 #pragma unroll
-                for (int a = 0; a < N; a++) d[u].R[a] = Rf[a * planeR + off];
-                if (s + L <= se) {  // the ring started at t+1 ends inside the processed range
-                    const int64_t offq = (int64_t)(L + s1) * ncol + c;
+            for (int a = 0; a < N; a++) xv[a] = Q[a * planeQ + offq];
+            d[u].y = live ? yv : 0.0;
 #pragma unroll
-                    for (int a = 0; a < N; a++) d[u].X[a] = Q[a * planeQ + offq];
-                }
+            for (int a = 0; a < N; a++) {
+                d[u].R[a] = live ? rv[a] : 0.0;
+                d[u].X[a] = hasq ? xv[a] : 0.0;
             }
         }
     };
@@ -210,22 +220,28 @@ __global__ __launch_bounds__(64) void k_bwd_chain(RingGeom g, EParams<N> ep,
                         lw[a] = cur[u].R[a] + cur[u].X[a];
                         m = fmax(m, lw[a]);
                     }
-                    const double E0 = fexp(v0 - m);
-                    double E[N];
+                    double ev[N + 1];
+                    ev[N] = v0 - m;
 #pragma unroll
-                    for (int a = 0; a < N; a++) E[a] = fexp(lw[a] - m);
-                    double ssum = E0 * ep.p00;
+                    for (int a = 0; a < N; a++) ev[a] = lw[a] - m;
+                    fexp_n<N + 1>(ev);
+                    const double E0 = ev[N];
+                    double sv[N + 1];
+                    sv[N] = E0 * ep.p00;
 #pragma unroll
-                    for (int a = 0; a < N; a++) ssum = __builtin_fma(E[a], ep.p0[a], ssum);
+                    for (int a = 0; a < N; a++) sv[N] = __builtin_fma(ev[a], ep.p0[a], sv[N]);
 #pragma unroll
                     for (int a = 0; a < N; a++) {
                         double su = E0 * ep.pend[a];
 #pragma unroll
                         for (int b = 0; b < N; b++)
-                            if (b != a) su = __builtin_fma(E[b], ep.px[a * N + b], su);
-                        Yn[a] = m + flog(su);
+                            if (b != a) su = __builtin_fma(ev[b], ep.px[a * N + b], su);
+                        sv[a] = su;
                     }
-                    lb0 = m + flog(ssum);
+                    flog_n<N + 1>(sv);
+#pragma unroll
+                    for (int a = 0; a < N; a++) Yn[a] = m + sv[a];
+                    lb0 = m + sv[N];
                 }
                 const int64_t offq = (int64_t)(s + 1) * ncol + c;  // onset index s-L+1 -> row s+1
 #pragma unroll
@@ -344,18 +360,26 @@ __global__ __launch_bounds__(64) void k_post(RingGeom g, JParams<N> jp,
             const int64_t offp = (int64_t)(H + s) * ncol + c, offq = (int64_t)(L + s) * ncol + c;
             const double a0 = A0[(int64_t)(1 + s) * ncol + c];
             const double la_prev = A0[off];                   // la0(t-1) in this chain's frame
-            const double ga = fexp((a0 + B0[off]) - z);        // gamma_t(silent)
+            double ex[2 * N + 1];
+            ex[2 * N] = (a0 + B0[off]) - z;                   // gamma_t(silent)
+#pragma unroll
+            for (int a = 0; a < N; a++) {
+                const double ly = Q[a * planeQ + offq];
+                ex[a] = (P[a * planeP + offp] + ly) - z;      // rho_a(t)
+                // xi: silent(t-1) -> (a,1)(t)   baumwelch.jl:240
+                ex[N + a] = t >= 1 ? (((la_prev + jp.c0[a]) + Rf[a * planeR + off]) + ly) - z : -INFINITY;
+            }
+            fexp_n<2 * N + 1>(ex);
+            const double ga = ex[2 * N];
             const double yv = yT[off];
             s_all += ga;                                      // baumwelch.jl:303 qq
             if (t < g.T - 1) s_m += ga;                       // :257 bb, t = 1..T-1
             s_y2 += ga * (yv * yv);                           // :302 with the new silent mean (= 0)
 #pragma unroll
             for (int a = 0; a < N; a++) {
-                const double ly = Q[a * planeQ + offq];
-                rv[a] = fexp((P[a * planeP + offp] + ly) - z);
-                ra[a] += rv[a];
-                if (t >= 1)                                   // xi: silent(t-1) -> (a,1)(t)   :240
-                    sx[a] += fexp((((la_prev + jp.c0[a]) + Rf[a * planeR + off]) + ly) - z);
+                rv[a] = ex[a];
+                ra[a] += ex[a];
+                sx[a] += ex[N + a];
             }
         }
 #pragma unroll
@@ -403,9 +427,12 @@ __global__ __launch_bounds__(64) void k_gsum(RingGeom g, const double *__restric
     const int64_t tb = (int64_t)c * B;
     const int64_t planeR = (int64_t)B * ncol;
     const bool active = c < g.nch;
-    auto Y = [&](int r) -> double {                // y[tb + r]
-        if (!active || tb + r >= g.T) return 0.0;
-        return (r < B) ? yT[(int64_t)r * ncol + c] : yT[(int64_t)(r - B) * ncol + c + 1];
+    auto Y = [&](int r) -> double {                // y[tb + r], 0 past the end (unconditional load)
+        const bool ok = active && tb + r < g.T;
+        const int rr = ok ? r : 0;
+        const int cc = active ? c : 0;
+        const double v = (rr < B) ? yT[(int64_t)rr * ncol + cc] : yT[(int64_t)(rr - B) * ncol + cc + 1];
+        return ok ? v : 0.0;
     };
     double g1[N][KB], g2[N][KB], w[KB];
 #pragma unroll

@@ -48,26 +48,30 @@ __global__ __launch_bounds__(64) void k_vit_chain(RingGeom g, JParams<N> jp,
     const int s0 = (c == 0) ? 0 : -H;
     const int64_t planeR = (int64_t)B * ncol, planeP = (int64_t)(H + B) * ncol;
     const int64_t planePsi = (int64_t)B * ncol;
-    const int cin = c > 0 ? c - 1 : 0;
-
+    // Loads are unconditional (idle lanes read a clamped, valid address and discard the value):
+    // straight-line loads let the compiler count vmcnt exactly, so a batch only waits for its
+    // own data while the next batch's loads stay in flight.
     auto load = [&](VitIn<N>(&d)[U], int sb) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int s = sb + u;
             const bool live = active && s >= s0 && s < nc;
-            d[u].y = 0.0;
+            const int sc = live ? s : 0;             // clamped step
+            const int cc = active ? c : 0;           // clamped column
+            const int64_t off = (sc >= 0) ? (int64_t)sc * ncol + cc : (int64_t)(B + sc) * ncol + (cc > 0 ? cc - 1 : 0);
+            const bool hasx = live && (s - L >= -H);
+            const int64_t offp = (int64_t)(hasx ? H + s - L : H) * ncol + cc;
+            const double yv = yT[off];
+            double rv[N], xv[N];
 #pragma unroll
-            for (int a = 0; a < N; a++) { d[u].R[a] = 0.0; d[u].X[a] = -INFINITY; }
-            if (live) {
-                const int64_t off = (s >= 0) ? (int64_t)s * ncol + c : (int64_t)(B + s) * ncol + cin;
-                d[u].y = yT[off];
+            for (int a = 0; a < N; a++) rv[a] = Rf[a * planeR + off];
 #pragma unroll
-                for (int a = 0; a < N; a++) d[u].R[a] = Rf[a * planeR + off];
-                if (s - L >= -H) {
-                    const int64_t offp = (int64_t)(H + s - L) * ncol + c;
+            for (int a = 0; a < N; a++) xv[a] = P[a * planeP + offp];
+            d[u].y = live ? yv : 0.0;
 #pragma unroll
-                    for (int a = 0; a < N; a++) d[u].X[a] = P[a * planeP + offp];
-                }
+            for (int a = 0; a < N; a++) {
+                d[u].R[a] = live ? rv[a] : 0.0;
+                d[u].X[a] = hasx ? xv[a] : -INFINITY;
             }
         }
     };
@@ -225,17 +229,18 @@ __global__ __launch_bounds__(64) void k_vit_backtrace(RingGeom g, const uint32_t
         if (fs > 0) { a = (fs - 1) / L; k = (fs - 1) % L + 1; }
     }
     const int64_t plane = (int64_t)B * ncol;
-    auto load = [&](uint32_t(&d)[UB][W], int sb) {  // steps sb, sb-1, ..., sb-UB+1
+    auto load = [&](uint32_t(&d)[UB][W], int sb) {  // steps sb, sb-1, ..., sb-UB+1 (unconditional)
 #pragma unroll
         for (int u = 0; u < UB; u++) {
             const int s = sb - u;
             const bool need = active && s <= se && s >= 0 && (tc + s) >= 1;
+            const int sc = need ? s : 0;
+            const int cc = active ? c : 0;
+            const int64_t off = (sc < B) ? (int64_t)sc * ncol + cc : (int64_t)(sc - B) * ncol + cc + 1;
 #pragma unroll
-            for (int w = 0; w < W; w++) d[u][w] = 0u;
-            if (need) {
-                const int64_t off = (s < B) ? (int64_t)s * ncol + c : (int64_t)(s - B) * ncol + c + 1;
-#pragma unroll
-                for (int w = 0; w < W; w++) d[u][w] = psi[w * plane + off];
+            for (int w = 0; w < W; w++) {
+                const uint32_t v = psi[w * plane + off];
+                d[u][w] = need ? v : 0u;
             }
         }
     };
