@@ -44,6 +44,25 @@ def algorithmic_bytes(kernel, S, T):
     return per_sample * T
 
 
+def measured_traffic(kernel, T, block, halo):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same
+    command (profiles/<tag>_summary.json, written by profiles/summarize.py from separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction).  None when no
+    summary matches the workload."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        meta = d.get("_meta", {})
+        if meta.get("samples") == T and meta.get("block") == block and meta.get("halo") == halo \
+                and kernel in d:
+            best = (d[kernel]["hbm_read_bytes"] + d[kernel]["hbm_write_bytes"], os.path.basename(path))
+    return best
+
+
 def cpu_baseline(H, N, K, temps, pp, sigma):
     """The oracle (literal restatement of the reference loops, single thread -- the reference has
     no threading) timed on a bounded sample of the same workload: Viterbi on one 100 000-sample
@@ -163,6 +182,7 @@ def main():
     dom = max(ksum, key=ksum.get)
     achieved = algorithmic_bytes(dom, S, T) / (ksum[dom] * 1e-3) / 1e9
     step_ms_kernels = sum(v[0] for v in prof.values()) / max(1, min(args.steps, 5))
+    traffic = measured_traffic(dom, T, info["block"], info["halo"])
 
     # split timings (untimed region): Viterbi only / E-step only
     def timed(fn, n=3):
@@ -192,12 +212,16 @@ def main():
                        "engine": "ring", "block": info["block"], "halo": info["halo"],
                        "chains": info["nchains"], "seed": 1234, "pooled_allreduce": bool(args.pooled)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
+                         "traffic_GBps": (traffic[0] / (ksum[dom] * 1e-3) / 1e9) if traffic else None,
                          "avg_launch_ms": ksum[dom],
                          "note": "achieved = SURVEY 8(d) algorithmic bytes of the sweep this kernel "
-                                 "implements / HIP-event launch time; the ring engine keeps the "
-                                 "trellis on chip (junction-only), so frac > 1 is expected; measured "
-                                 "HBM traffic: profiles/"},
+                                 "implements (a trellis-materialising sweep) / HIP-event launch time; "
+                                 "the ring engine never writes the trellis (junction-only recursion), "
+                                 "so frac > 1; traffic = HBM bytes per launch actually moved "
+                                 "(rocprofv3 PMC), traffic_GBps = that over the same launch time"},
             "detail": {"viterbi_Msamples_s": T / t_vit / 1e6, "estep_Msamples_s": T / t_est / 1e6,
                        "kernel_ms": {k: round(v, 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1])},
                        "sum_kernel_ms_per_step": step_ms_kernels,

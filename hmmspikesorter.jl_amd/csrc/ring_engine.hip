@@ -27,9 +27,10 @@ bool ring_supported(const HostModel &m, int64_t T, std::string *why)
 static int make_geometry(RingGeom &g, int64_t T, int N, int L, int64_t block_req, int64_t halo_req)
 {
     g.T = T; g.N = N; g.L = L;
-    // warm-up: four ring lengths, at least 256 samples.  Whether a warm-up was long enough is
-    // CHECKED on device after every call (k_halo_check, k_fb_check); the host-buffer entry points
-    // double it and retry when a check fails (DESIGN.md "warm-up").
+    // warm-up: four ring lengths, at least 256 samples (scripts/sweep_halo.py: at 10 M samples the
+    // certificates pass at 256 on sparse and dense signals, 128 is flagged 4..64 times).  Whether
+    // a warm-up was long enough is CERTIFIED on device after every call (k_halo_check,
+    // k_fb_check); the host-buffer entry points double it and retry when a certificate fails.
     int64_t H = halo_req > 0 ? halo_req : std::max<int64_t>(256, 4 * (int64_t)L);
     H = round_up(std::max<int64_t>(H, L + 40), 64);  // the boundary checks need L+8 settled steps
     // chain length: twice the warm-up, or longer when the signal alone fills 1024 SIMDs x 64 lanes
@@ -265,9 +266,12 @@ __global__ __launch_bounds__(256) void k_prepass(RingGeom g, const double *__res
     const int64_t tbase = (int64_t)c * B + s0;
     const bool cact = c < g.nch;
     auto Y = [&](int j) -> double {  // y[tbase + j]; 0 past the end of the data (truncated rings)
-        if (!cact || tbase + j >= T) return 0.0;
-        const int row = s0 + j;
-        return (row < B) ? yT[(int64_t)row * ncol + c] : yT[(int64_t)(row - B) * ncol + c + 1];
+        const bool ok = cact && tbase + j < T;        // unconditional load from a clamped address
+        const int row = ok ? s0 + j : 0;
+        const int cc = cact ? c : 0;
+        const int64_t o = (row < B) ? (int64_t)row * ncol + cc : (int64_t)(row - B) * ncol + cc + 1;
+        const double v = yT[o];
+        return ok ? v : 0.0;
     };
     // sum_k (y - m)^2 = sum y^2 - 2 sum y*m + sum m^2 : one fma per (window, ring, phase).
     // Phase-outer loop: the mean of phase k is wave-uniform (N scalar loads per phase) and the RS

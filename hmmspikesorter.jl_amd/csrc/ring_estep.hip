@@ -431,7 +431,8 @@ __global__ __launch_bounds__(64) void k_gsum(RingGeom g, const double *__restric
         const bool ok = active && tb + r < g.T;
         const int rr = ok ? r : 0;
         const int cc = active ? c : 0;
-        const double v = (rr < B) ? yT[(int64_t)rr * ncol + cc] : yT[(int64_t)(rr - B) * ncol + cc + 1];
+        const int64_t o = (rr < B) ? (int64_t)rr * ncol + cc : (int64_t)(rr - B) * ncol + cc + 1;
+        const double v = yT[o];
         return ok ? v : 0.0;
     };
     double g1[N][KB], g2[N][KB], w[KB];

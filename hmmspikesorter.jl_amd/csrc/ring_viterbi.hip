@@ -14,6 +14,7 @@
 // of the reference's O(T) cumulative sum, whose own rounding unit is larger).  A decoded path can
 // therefore differ from the reference only where two alternatives tie within rounding noise of
 // the reference itself.  hmmsort_set_option("engine", STRICT) gives the op-for-op engine.
+#include <algorithm>
 #include <cmath>
 #include <type_traits>
 
@@ -328,36 +329,62 @@ __global__ void k_stitch_fix(RingGeom g, const uint32_t *__restrict__ psi, int16
 
 // Boundary certificate of the Viterbi warm-up.  Chain c's warm-up and chain c-1's own sweep both
 // computed delta(silent) at tc-1 and the L onsets per ring still inside their rings.  Back-pointer
-// decisions depend only on DIFFERENCES between those entries, so if every entry of the warm-up
-// equals its counterpart up to one common constant, all decisions of chain c are those of a
-// sequential sweep.  (Every entry is finite: an onset's score is at least delta(silent)+lp.)
-// Block = 64 boundaries x 8 entry subsets; flagged boundaries are counted in diag[0], the largest
-// spread goes to diag[2] (bit pattern of a double).
+// decisions depend only on DIFFERENCES between those entries, so if every RELEVANT entry of the
+// warm-up equals its counterpart up to one common constant, all decisions of chain c are those of
+// a sequential sweep.  An in-flight onset is provably irrelevant when, in both frames, it loses
+// every competition at the moment it leaves its ring to the path that simply stays silent from
+// tc-1 on:  P_a(t') + kappa_a < delta(silent, tc-1) + sum_{t=tc..te}(c00 + q_t(silent)) - 1e-6,
+// te = t'+L-1, kappa_a = max_j [lp((a,L)->j) - lp(silent->j)].  (Every entry is finite: an
+// onset's score is at least delta(silent)+lp.)  Block = 64 boundaries x 8 entry subsets; flagged
+// boundaries are counted in diag[0], the largest relevant spread goes to diag[2].
 constexpr int kVChkParts = 8;
 
-__global__ __launch_bounds__(64 * kVChkParts) void k_halo_check(RingGeom g, double tol,
+struct KappaArg { double c00, mean0, den; double kappa[kRingMaxN]; };
+
+__global__ __launch_bounds__(64 * kVChkParts) void k_halo_check(RingGeom g, KappaArg ka, double tol,
+                                                               const double *__restrict__ yT,
                                                                const double *__restrict__ P,
                                                                const double *__restrict__ D0pre,
                                                                const double *__restrict__ D0end,
                                                                int64_t *__restrict__ diag)
 {
+    extern __shared__ double pre[];  // [L][64] prefix sums of (c00 + q_t(silent)), t = tc..tc+i
     __shared__ double shlo[kVChkParts][64], shhi[kVChkParts][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const bool on = c >= 1 && c < g.nch;
     const int B = g.B, H = g.H, L = g.L, N = g.N, ncol = g.ncol;
     const int64_t planeP = (int64_t)(H + B) * ncol;
+    const int cc = on ? c : 1;
+    for (int i = part; i < L; i += kVChkParts) {
+        const int64_t t = (int64_t)cc * B + i;
+        double v = 0.0;
+        if (t < g.T) { const double d = yT[(int64_t)i * ncol + cc] - ka.mean0; v = ka.c00 - (d * d) / ka.den; }
+        pre[i * 64 + lane] = v;
+    }
+    __syncthreads();
+    if (part == 0) {
+        double acc = 0.0;
+        for (int i = 0; i < L; i++) { acc += pre[i * 64 + lane]; pre[i * 64 + lane] = acc; }
+    }
+    __syncthreads();
     double lo = INFINITY, hi = -INFINITY;
     if (on) {
-        if (part == 0) { const double d = D0pre[c] - D0end[c - 1]; lo = d; hi = d; }
+        const double dh = D0pre[c], dm = D0end[c - 1];
+        if (part == 0) { const double d = dh - dm; lo = d; hi = d; }
         for (int a = 0; a < N; a++)
 #pragma unroll 4
             for (int j = 1 + part; j <= L; j += kVChkParts) {
                 const double hv = P[a * planeP + (int64_t)(H - j) * ncol + c];
                 const double mv = P[a * planeP + (int64_t)(H + B - j) * ncol + c - 1];
-                const double d = (hv == mv) ? 0.0 : hv - mv;
-                lo = fmin(lo, d); hi = fmax(hi, d);
-                if (d != d) hi = INFINITY;  // NaN -> flagged
+                // silent-stay path up to the exit time te = tc + (L-1-j)
+                const double sil = (j < L) ? pre[(L - 1 - j) * 64 + lane] : 0.0;
+                const bool dead = (hv + ka.kappa[a] < dh + sil - 1e-6) && (mv + ka.kappa[a] < dm + sil - 1e-6);
+                if (!dead) {
+                    const double d = (hv == mv) ? 0.0 : hv - mv;
+                    lo = fmin(lo, d); hi = fmax(hi, d);
+                    if (d != d) hi = INFINITY;  // NaN -> flagged
+                }
             }
     }
     shlo[part][lane] = lo; shhi[part][lane] = hi;
@@ -495,8 +522,19 @@ int ring_viterbi_launch(RingDev *r, const double *d_y, int16_t *d_x, double *d_l
                        r->bstate, r->redo); }
     { PROF(r, "k_stitch_fix", st); hipLaunchKernelGGL(k_stitch_fix, dim3(1), dim3(64), 0, st, g, r->psi, r->xT, r->bstate, r->redo,
                        r->diag); }
-    { PROF(r, "k_halo_check", st); hipLaunchKernelGGL(k_halo_check, dim3(g.ncol / 64), dim3(64 * kVChkParts), 0, st, g, 1e-6, r->P,
-                       r->D0pre, r->D0end, r->diag); }
+    {
+        KappaArg ka;
+        ka.c00 = r->ring.c00; ka.mean0 = r->mean[0]; ka.den = r->den;
+        for (int a = 0; a < g.N; a++) {
+            double k = r->ring.cend[a] - r->ring.c00;
+            for (int b = 0; b < g.N; b++)
+                if (b != a) k = std::max(k, r->ring.cx[a * g.N + b] - r->ring.c0[b]);
+            ka.kappa[a] = k;
+        }
+        PROF(r, "k_halo_check", st);
+        hipLaunchKernelGGL(k_halo_check, dim3(g.ncol / 64), dim3(64 * kVChkParts), (size_t)g.L * 64 * sizeof(double), st,
+                           g, ka, 1e-6, r->yT, r->P, r->D0pre, r->D0end, r->diag);
+    }
     { PROF(r, "k_transpose_x", st); hipLaunchKernelGGL(k_transpose_x, dim3(g.B / 64, g.ncol / 64), dim3(256), 0, st, r->xT, g.T,
                        g.B, g.ncol, d_x); }
     { PROF(r, "k_ll_partial", st); hipLaunchKernelGGL(k_ll_partial, dim3(r->nparts), dim3(256), 0, st, g, d_y, d_x, r->d_mean,

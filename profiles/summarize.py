@@ -8,6 +8,7 @@ read side is doubled (checked here against the kernels' own byte counts: the for
 9 doubles per lane-step over 2*T lane-steps = 1.44 GB, FETCH_SIZE*2 = 1.43 GB); WRITE_SIZE is exact.
 
 usage: summarize.py <tag> <kernel_stats.csv> <fetch_counter_collection.csv> <write_counter_collection.csv>
+                    [samples block halo]
 """
 import collections
 import csv
@@ -45,11 +46,15 @@ def main():
         out[name] = {"calls": calls, "avg_ms": round(avg_ms, 4), "pct": pct,
                      "hbm_read_bytes": rd, "hbm_write_bytes": ww,
                      "hbm_GBps": round((rd + ww) / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None}
+    if len(sys.argv) >= 8:
+        out["_meta"] = {"samples": int(sys.argv[5]), "block": int(sys.argv[6]), "halo": int(sys.argv[7]),
+                        "command": "python3 bench.py (N=4, K=60 model, one channel)"}
     here = os.path.dirname(os.path.abspath(__file__))
     json.dump(out, open(os.path.join(here, tag + "_summary.json"), "w"), indent=1)
     with open(os.path.join(here, tag + "_summary.md"), "w") as f:
         f.write("| kernel | launches | avg ms | %% of GPU time | HBM read MB (FETCH_SIZE x2) | HBM write MB | HBM GB/s |\n|---|---|---|---|---|---|---|\n")
-        for k, v in sorted(out.items(), key=lambda kv: -kv[1]["avg_ms"] * kv[1]["calls"]):
+        for k, v in sorted(((k, v) for k, v in out.items() if k != "_meta"),
+                           key=lambda kv: -kv[1]["avg_ms"] * kv[1]["calls"]):
             f.write("| %s | %d | %.4f | %.2f | %.1f | %.1f | %s |\n" % (
                 k, v["calls"], v["avg_ms"], v["pct"], v["hbm_read_bytes"] / 1e6,
                 v["hbm_write_bytes"] / 1e6, v["hbm_GBps"]))
