@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--samples", type=int, default=10_000_000, help="samples per channel")
     ap.add_argument("--pooled", action="store_true", help="all-reduce E-step statistics (extension)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--halo", type=int, default=0)
     args = ap.parse_args()
@@ -110,7 +111,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("HMMSORT_BENCH_ONE_GPU"):   # rehearsal: all ranks on GPU 0 (gloo only)
+            local_rank = 0
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     assert world == args.gpus, "launch one process per GPU (WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -143,7 +149,12 @@ def main():
         plan.viterbi(dy, dx, dll, stream)
         plan.estep(dy, stats, stream)
         if args.pooled and dist is not None:
-            dist.all_reduce(stats)
+            if args.backend == "nccl":
+                dist.all_reduce(stats)
+            else:                                  # gloo rehearsal: reduce through the host
+                h = stats.cpu()
+                dist.all_reduce(h)
+                stats.copy_(h)
         plan.mstep(stats, out, stream)
         plan.unbind()
 
@@ -162,7 +173,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     # boundary certificates: Viterbi calls fill diag[0..2], E-step calls diag[3..6]
