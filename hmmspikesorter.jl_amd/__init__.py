@@ -7,7 +7,8 @@ import it through the root-level shim:  `import hmmsort_amd`.
 from . import _lib, dist, synth
 from ._lib import (ENGINE_AUTO, ENGINE_RING, ENGINE_STRICT, HmmsortError, device_count,
                    get_option, set_option)
-from .api import (HMMSpikeTemplateModel, HMMSpikingModel, StateMatrix, backward, fit, forward,
+from .api import (HMMSpikeTemplateModel, HMMSpikingModel, StateMatrix, backward, extract_spiketimes,
+                  fit, forward,
                   predict, reconstruct_signal, train_model, train_step, unroll_mlseq, update,
                   viterbi)
 from .device import Plan
@@ -15,6 +16,6 @@ from .synth import create_signal, create_spike_template
 
 __all__ = ["StateMatrix", "HMMSpikeTemplateModel", "HMMSpikingModel", "forward", "backward",
            "update", "train_model", "train_step", "viterbi", "reconstruct_signal", "unroll_mlseq",
-           "fit", "predict", "Plan", "create_signal", "create_spike_template", "HmmsortError",
+           "fit", "predict", "extract_spiketimes", "Plan", "create_signal", "create_spike_template", "HmmsortError",
            "set_option", "get_option", "device_count", "ENGINE_AUTO", "ENGINE_STRICT",
            "ENGINE_RING"]

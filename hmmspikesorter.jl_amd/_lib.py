@@ -49,6 +49,7 @@ SIGNATURES = {
                                _i64, _pi64, _vp]),
     "hmmsort_reconstruct": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "hmmsort_unroll_mlseq": (_int, [_vp, _i64, _vp, _i64, _i64, _vp]),
+    "hmmsort_extract_spiketimes": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "hmmsort_plan_create": (_int, [C.POINTER(_vp), _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp,
                                    _f64]),
     "hmmsort_plan_set_model": (_int, [_vp, _vp, _i64, _vp, _f64]),

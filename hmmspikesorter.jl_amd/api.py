@@ -300,3 +300,22 @@ def predict(model):
     """StatsBase.predict(model)   fit.jl:54-56."""
     tm = model.template_model
     return reconstruct_signal(model.ml_seq, tm.state_matrix, tm.mu, tm.sigma)
+
+
+def extract_spiketimes(model):
+    """extract_spiketimes(model::HMMSpikingModel) -> one array of spike sample indices per neuron
+    (1-based like the reference's findin result)   extraction.jl:15-24."""
+    tm = model.template_model
+    lA = tm.state_matrix
+    x = np.ascontiguousarray(model.ml_seq, dtype=np.int16)
+    mu = np.asfortranarray(tm.mu, dtype=np.float64)
+    st = np.asfortranarray(lA.states, dtype=np.int16)
+    cap = max(1, len(x) // 8)
+    while True:
+        times = np.zeros((lA.N, cap), dtype=np.int64)
+        counts = np.zeros(lA.N, dtype=np.int64)
+        check(lib().hmmsort_extract_spiketimes(ptr(x), len(x), ptr(st), lA.N, lA.nstates, ptr(mu),
+                                               mu.shape[0], ptr(times), cap, ptr(counts)))
+        if counts.max(initial=0) <= cap:
+            return [times[i, :counts[i]].copy() for i in range(lA.N)]
+        cap = int(counts.max())

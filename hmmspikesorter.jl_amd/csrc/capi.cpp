@@ -539,4 +539,57 @@ int hmmsort_unroll_mlseq(const int16_t *mlseq, int64_t T, const int16_t *states,
     return HMMSORT_OK;
 }
 
+int hmmsort_extract_spiketimes(const int16_t *mlseq, int64_t T, const int16_t *states, int64_t N,
+                               int64_t S, const double *mu, int64_t K, int64_t *times_out,
+                               int64_t cap, int64_t *counts_out)
+{
+    HS_CHECK(states && mu && counts_out && (T == 0 || mlseq) && (cap == 0 || times_out), HMMSORT_EINVAL,
+             "extract_spiketimes: null argument");
+    HS_CHECK(N >= 1 && N <= 32 && S >= 1 && K >= 1 && T >= 0 && cap >= 0, HMMSORT_EINVAL,
+             "extract_spiketimes: bad sizes");
+    for (int64_t i = 0; i < N; i++) counts_out[i] = 0;
+    if (T == 0) return HMMSORT_OK;
+    int rc = need_device();
+    if (rc) return rc;
+    // indmin(mu[:,i]): first minimum (extraction.jl:18); match table per state
+    std::vector<uint32_t> match(S, 0u);
+    for (int64_t i = 0; i < N; i++) {
+        int64_t q = 0;
+        for (int64_t k = 1; k < K; k++)
+            if (mu[k + K * i] < mu[q + K * i]) q = k;
+        for (int64_t j = 0; j < S; j++)
+            if (states[i + N * j] == q + 1) match[j] |= (1u << i);
+    }
+    const int64_t nb = (T + kSpikeChunkHost - 1) / kSpikeChunkHost;
+    DevBuf dx, dm, dcnt, doff, dt;
+    if ((rc = dx.alloc(T * sizeof(int16_t))) || (rc = dm.alloc(S * sizeof(uint32_t))) ||
+        (rc = dcnt.alloc(nb * N * sizeof(int64_t))) || (rc = doff.alloc(nb * N * sizeof(int64_t))) ||
+        (rc = dt.alloc(std::max<int64_t>(1, N * cap) * sizeof(int64_t))))
+        return rc;
+    HS_HIP(hipMemcpy(dx.p, mlseq, T * sizeof(int16_t), hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(dm.p, match.data(), S * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if ((rc = dev_spike_compact(dx.as<int16_t>(), T, dm.as<uint32_t>(), (int)N, (int)S, 0,
+                                dcnt.as<int64_t>(), nullptr, nullptr, cap, nullptr)))
+        return rc;
+    std::vector<int64_t> cnt(nb * N), off(nb * N);
+    HS_HIP(hipMemcpy(cnt.data(), dcnt.p, cnt.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < N; i++) {
+        int64_t acc = 0;
+        for (int64_t b = 0; b < nb; b++) { off[b * N + i] = acc; acc += cnt[b * N + i]; }
+        counts_out[i] = acc;
+    }
+    if (cap == 0) return HMMSORT_OK;
+    HS_HIP(hipMemcpy(doff.p, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    if ((rc = dev_spike_compact(dx.as<int16_t>(), T, dm.as<uint32_t>(), (int)N, (int)S, 1,
+                                dcnt.as<int64_t>(), doff.as<int64_t>(), dt.as<int64_t>(), cap, nullptr)))
+        return rc;
+    HS_HIP(hipDeviceSynchronize());
+    for (int64_t i = 0; i < N; i++) {
+        const int64_t n = std::min(counts_out[i], cap);
+        HS_HIP(hipMemcpy(times_out + i * cap, dt.as<int64_t>() + i * cap, n * sizeof(int64_t),
+                         hipMemcpyDeviceToHost));
+    }
+    return HMMSORT_OK;
+}
+
 }  // extern "C"

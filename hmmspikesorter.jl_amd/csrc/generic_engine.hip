@@ -250,6 +250,62 @@ __global__ void k_unroll(const int16_t *__restrict__ x, int64_t T,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// extract_spiketimes (extraction.jl:15-24): ordered stream compaction.  match[j] has bit i set
+// when state j puts neuron i at the row of its template minimum.  Block b owns samples
+// [b*CH, (b+1)*CH); pass 0 counts per (block, neuron), the host turns the counts into offsets,
+// pass 1 writes the 1-based sample indices in ascending order.
+// ------------------------------------------------------------------------------------------
+constexpr int kSpikeChunk = 4096;
+
+__global__ __launch_bounds__(256) void k_spike_compact(const int16_t *__restrict__ x, int64_t T,
+                                                       const uint32_t *__restrict__ match, int N,
+                                                       int S, int pass, int64_t *__restrict__ cnt,
+                                                       const int64_t *__restrict__ offs,
+                                                       int64_t *__restrict__ times, int64_t cap)
+{
+    __shared__ int wsum[4];
+    __shared__ long long run;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kSpikeChunk;
+    for (int i = 0; i < N; i++) {
+        if (threadIdx.x == 0) run = 0;
+        __syncthreads();
+        for (int sub = 0; sub < kSpikeChunk; sub += 256) {
+            const int64_t t = base + sub + threadIdx.x;
+            int xs = (t < T) ? x[t] : 0;
+            const bool hit = xs >= 1 && xs <= S && ((match[xs - 1] >> i) & 1u);
+            const unsigned long long bm = __ballot(hit);
+            const int before = __popcll(bm & ((1ull << lane) - 1ull));
+            if (lane == 0) wsum[wv] = __popcll(bm);
+            __syncthreads();
+            int woff = 0;
+            for (int w = 0; w < wv; w++) woff += wsum[w];
+            const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (pass == 1 && hit) {
+                const int64_t pos = offs[(int64_t)blockIdx.x * N + i] + run + woff + before;
+                if (pos < cap) times[(int64_t)i * cap + pos] = t + 1;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) run += tot;
+            __syncthreads();
+        }
+        if (pass == 0 && threadIdx.x == 0) cnt[(int64_t)blockIdx.x * N + i] = run;
+        __syncthreads();
+    }
+}
+
+int dev_spike_compact(const int16_t *d_x, int64_t T, const uint32_t *d_match, int N, int S, int pass,
+                      int64_t *d_cnt, const int64_t *d_offs, int64_t *d_times, int64_t cap,
+                      hipStream_t st)
+{
+    const int nb = (int)((T + kSpikeChunk - 1) / kSpikeChunk);
+    hipLaunchKernelGGL(k_spike_compact, dim3(nb), dim3(256), 0, st, d_x, T, d_match, N, S, pass, d_cnt,
+                       d_offs, d_times, cap);
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
 int dev_reconstruct(const int16_t *d_x, int64_t T, const int16_t *d_states, int64_t N, int64_t S,
                     const double *d_mu, int64_t K, double *d_out, hipStream_t st)
 {

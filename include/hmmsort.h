@@ -124,6 +124,15 @@ int hmmsort_reconstruct(const int16_t *x, int64_t T, const int16_t *states, int6
 int hmmsort_unroll_mlseq(const int16_t *mlseq, int64_t T, const int16_t *states, int64_t N,
                          int64_t S, int16_t *out);
 
+/* extract_spiketimes(model)                                              extraction.jl:15-24
+ * For neuron i the spike time is every sample whose decoded state has neuron i at the row of its
+ * template minimum (indmin(mu[:,i]), first minimum).  times_out is N rows of `cap` entries
+ * (1-based sample indices, ascending, as Julia's findin returns them); counts_out[i] is the total
+ * number found (entries beyond cap are dropped: call again with a larger cap). */
+int hmmsort_extract_spiketimes(const int16_t *mlseq, int64_t T, const int16_t *states, int64_t N,
+                               int64_t S, const double *mu, int64_t K, int64_t *times_out,
+                               int64_t cap, int64_t *counts_out);
+
 /* ---- device-resident plan API --------------------------------------------------------- */
 /* Used by bench.py and by multi-GPU hosts: the signal stays in HBM, the caller owns device
  * buffers (plain device pointers) and the HIP stream (passed as void* == hipStream_t; NULL =

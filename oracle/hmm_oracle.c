@@ -439,3 +439,25 @@ int hmm_oracle_fit_chunked(const double *X, int64_t n, int64_t chunksize, const 
     *ll_out = ll;
     return 0;
 }
+
+/* extraction.jl:15-24  extract_spiketimes: for neuron i the spike time is every sample whose
+ * decoded state has neuron i at the row of its template minimum (indmin = first minimum).
+ * times is N x cap (row per neuron), 1-based sample indices ascending; counts[i] = total found. */
+void hmm_oracle_extract_spiketimes(const int16_t *ml_seq, int64_t T, const int16_t *states1,
+                                   int64_t N, int64_t S, const double *mu, int64_t K,
+                                   int64_t *times, int64_t cap, int64_t *counts)
+{
+    (void)S;
+    for (int64_t i = 0; i < N; i++) {
+        int64_t q = 0;
+        for (int64_t k = 1; k < K; k++)
+            if (mu[k + K * i] < mu[q + K * i]) q = k;
+        int64_t n = 0;
+        for (int64_t t = 0; t < T; t++)
+            if (states1[i + N * (ml_seq[t] - 1)] == q + 1) {
+                if (n < cap) times[i * cap + n] = t + 1;
+                n++;
+            }
+        counts[i] = n;
+    }
+}

@@ -62,6 +62,9 @@ def lib(path=None):
         L.hmm_oracle_reconstruct.argtypes = [_pi16, _i64, _pi16, _i64, _i64, _pf64, _i64, _pf64]
         L.hmm_oracle_unroll_mlseq.restype = None
         L.hmm_oracle_unroll_mlseq.argtypes = [_pi16, _i64, _pi16, _i64, _pi16]
+        L.hmm_oracle_extract_spiketimes.restype = None
+        L.hmm_oracle_extract_spiketimes.argtypes = [_pi16, _i64, _pi16, _i64, _i64, _pf64, _i64,
+                                                    _pi64, _i64, _pi64]
         L.hmm_oracle_fit_chunked.restype = C.c_int
         L.hmm_oracle_fit_chunked.argtypes = [_pf64, _i64, _i64] + model + [_pi16, _pf64]
         if path is not None:
@@ -220,3 +223,16 @@ def fit_chunked(X, sm, mu, sigma, chunksize):
     rc = lib().hmm_oracle_fit_chunked(_p(X, _pf64), len(X), int(chunksize),
                                       *sm._model_args(mu, sigma), _p(ml, _pi16), C.byref(ll))
     return rc, ml, ll.value
+
+
+def extract_spiketimes(ml_seq, sm, mu):
+    """extraction.jl:15-24 -> list of 1-based sample-index arrays, one per neuron."""
+    ml_seq = np.ascontiguousarray(ml_seq, np.int16)
+    mu = _mu(mu)
+    cap = len(ml_seq)
+    times = np.zeros((sm.N, cap), np.int64)
+    counts = np.zeros(sm.N, np.int64)
+    lib().hmm_oracle_extract_spiketimes(_p(ml_seq, _pi16), len(ml_seq), _p(sm.states, _pi16), sm.N,
+                                        sm.nstates, _p(mu, _pf64), mu.shape[0], _p(times, _pi64),
+                                        cap, _p(counts, _pi64))
+    return [times[i, :counts[i]].copy() for i in range(sm.N)]

@@ -165,3 +165,17 @@ def test_train_model_driver(O, H):
     for _ in range(3):
         osm, omu, osig, _, _ = O.train_step(y, osm, omu, osig)
     assert np.allclose(mu, omu, rtol=1e-8, atol=1e-11) and np.isclose(sig, osig, rtol=1e-9)
+
+
+def test_extract_spiketimes(O, H):
+    # extraction.jl:15-24: with and without overlap states
+    temps = two_templates(H, 30)
+    pp = [0.006, 0.004]
+    for ov, T in ((False, 40_000), (True, 6_000)):
+        sm = H.StateMatrix.create(2, 30, np.log(pp), ov)
+        y = H.create_signal(T, 0.3, pp, temps, seed=41)
+        model = H.fit(H.HMMSpikeTemplateModel(sm, temps, 0.3), y)
+        got = H.extract_spiketimes(model)
+        ref = O.extract_spiketimes(model.ml_seq, to_oracle_sm(O, sm), temps)
+        assert len(got) == 2 and all(np.array_equal(g, r) for g, r in zip(got, ref))
+        assert all(len(g) > 10 and np.all(np.diff(g) > 0) for g in got)
