@@ -36,6 +36,7 @@ def algorithmic_bytes(kernel, S, T):
     sweep: forward reads y (8) and writes alpha (8S); backward re-reads y and alpha (8S+8);
     Viterbi reads y (8), writes psi as Int16 per state (2S); backtrace reads >= 2 and writes x (2)."""
     per_sample = {
+        "k_fb_chain": 2 * (8 * S + 8),      # forward and backward sweeps in one launch
         "k_fwd_chain": 8 * S + 8,
         "k_bwd_chain": 8 * S + 8,
         "k_vit_chain": 2 * S + 8,

@@ -36,13 +36,13 @@ struct ChainIn {
 // The N+1 exponentials fexp(value - m) are shared by all N+1 junction sums.
 // ------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(64) void k_fwd_chain(RingGeom g, EParams<N> ep,
-                                                  const double *__restrict__ yT,
-                                                  const double *__restrict__ Rf,
-                                                  double *__restrict__ P, double *__restrict__ A0)
+__device__ __forceinline__ void fwd_chain_body(int bx, const RingGeom &g, const EParams<N> &ep,
+                                               const double *__restrict__ yT,
+                                               const double *__restrict__ Rf,
+                                               double *__restrict__ P, double *__restrict__ A0)
 {
     constexpr int U = chain_unroll<N>();
-    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int c = bx * 64 + threadIdx.x;
     const int B = g.B, H = g.H, L = g.L, ncol = g.ncol;
     const bool active = c < g.nch;
     const int64_t tc = (int64_t)c * B;
@@ -147,14 +147,14 @@ __global__ __launch_bounds__(64) void k_fwd_chain(RingGeom g, EParams<N> ep,
 // Q row (L + s') holds ly_a(tc + s'), s' in [-(L-1), B+H).
 // ------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(64) void k_bwd_chain(RingGeom g, EParams<N> ep,
-                                                  const double *__restrict__ yT,
-                                                  const double *__restrict__ Rf,
-                                                  double *__restrict__ Q, double *__restrict__ B0,
-                                                  double *__restrict__ B0h)
+__device__ __forceinline__ void bwd_chain_body(int bx, const RingGeom &g, const EParams<N> &ep,
+                                               const double *__restrict__ yT,
+                                               const double *__restrict__ Rf,
+                                               double *__restrict__ Q, double *__restrict__ B0,
+                                               double *__restrict__ B0h)
 {
     constexpr int U = chain_unroll<N>();
-    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int c = bx * 64 + threadIdx.x;
     const int B = g.B, H = g.H, L = g.L, ncol = g.ncol;
     const bool active = c < g.nch;
     const int64_t tc = (int64_t)c * B;
@@ -267,6 +267,22 @@ __global__ __launch_bounds__(64) void k_bwd_chain(RingGeom g, EParams<N> ep,
 //   rho_a(t') = fexp(lp_a + ly_a - Zc)  -> rhoT (transposed layout, zero where there is no onset);
 //   scalar sums: gamma_t(silent) (all t; t < T-1; times y^2), xi_a, sum_t' rho_a(t').
 // ------------------------------------------------------------------------------------------
+// Forward and backward sweeps are independent until the statistics; one launch runs both, the
+// forward chains on the even blocks and the backward chains on the odd ones, so 2 x (chains/64)
+// wavefronts share the 1024 SIMDs instead of running half-empty one after the other.
+template <int N>
+__global__ __launch_bounds__(64) void k_fb_chain(RingGeom g, EParams<N> ep,
+                                                 const double *__restrict__ yT,
+                                                 const double *__restrict__ Rf,
+                                                 double *__restrict__ P, double *__restrict__ A0,
+                                                 double *__restrict__ Q, double *__restrict__ B0,
+                                                 double *__restrict__ B0h)
+{
+    const int bx = blockIdx.x >> 1;
+    if (blockIdx.x & 1) bwd_chain_body<N>(bx, g, ep, yT, Rf, Q, B0, B0h);
+    else fwd_chain_body<N>(bx, g, ep, yT, Rf, P, A0);
+}
+
 constexpr int kZParts = 4;
 
 // partial log-sum-exp of the ring-state terms lp_a(t') + ly_a(t') over window rows
@@ -592,6 +608,105 @@ __global__ __launch_bounds__(64 * kChkParts) void k_fb_check(RingGeom g, double 
     }
 }
 
+// LDS-tiled variant of k_gsum for nkb = ceil(L/KB) <= 8 (512 threads keep 256 VGPRs per lane):
+// one workgroup = 64 chain columns, wave w = phase group w (surplus waves only help staging).
+// A tile of TR onset rows of rho (all rings) and the TR + nkb*KB - 1 rows of y they touch are
+// staged ONCE in LDS (coalesced global rows -> [row][lane], conflict-free reads) and consumed by
+// all phase groups, instead of every phase group streaming them from L2.  Staging goes through
+// registers so that all global loads of a tile are issued back to back.
+template <int N>
+__global__ __launch_bounds__(512) void k_gsum_lds(RingGeom g, int nkb, const double *__restrict__ yT,
+                                                  const double *__restrict__ rhoT,
+                                                  double *__restrict__ partG)
+{
+    constexpr int KB = gsum_kb<N>(), TR = 16;
+    constexpr int NRH = N * TR * 64 / 512;          // rho elements per thread and tile
+    constexpr int NYM = (TR + 8 * KB - 1 + 7) / 8;  // upper bound of y elements per thread and tile
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, kbi = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64;
+    const int B = g.B, L = g.L, ncol = g.ncol;
+    const int YR = TR + nkb * KB - 1;
+    double *lrho = lds;                       // [N][TR][64]
+    double *ly = lds + (size_t)N * TR * 64;   // [YR][64]
+    const int64_t planeR = (int64_t)B * ncol;
+    const int k0 = kbi * KB + 1;
+    double g1[N][KB], g2[N][KB], w[KB];
+#pragma unroll
+    for (int a = 0; a < N; a++)
+#pragma unroll
+        for (int j = 0; j < KB; j++) { g1[a][j] = 0.0; g2[a][j] = 0.0; }
+    for (int s0 = 0; s0 < B; s0 += TR) {
+        double tr_[NRH], ty_[NYM];
+#pragma unroll
+        for (int q = 0; q < NRH; q++) {
+            const int i = threadIdx.x + q * 512;
+            const int ln = i & 63, rest = i >> 6, u = rest % TR, a = rest / TR;
+            tr_[q] = rhoT[a * planeR + (int64_t)(s0 + u) * ncol + c0 + ln];
+        }
+#pragma unroll
+        for (int q = 0; q < NYM; q++) {
+            const int i = threadIdx.x + q * 512;
+            const int ln = i & 63, r = s0 + (i >> 6);
+            const int cc = c0 + ln;
+            const bool ok = i < YR * 64 && cc < g.nch && (int64_t)cc * B + r < g.T;
+            const int rr = ok ? r : 0, cq = ok ? cc : 0;
+            const int64_t o = (rr < B) ? (int64_t)rr * ncol + cq : (int64_t)(rr - B) * ncol + cq + 1;
+            const double v = yT[o];
+            ty_[q] = ok ? v : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NRH; q++) lrho[threadIdx.x + q * 512] = tr_[q];
+#pragma unroll
+        for (int q = 0; q < NYM; q++) {
+            const int i = threadIdx.x + q * 512;
+            if (i < YR * 64) ly[i] = ty_[q];
+        }
+        __syncthreads();
+        if (kbi >= nkb) continue;  // surplus waves only help staging (wave-uniform)
+        // window for onset row u: w[(u + j) % KB] = y[row s0 + u + k0 - 1 + j]
+#pragma unroll
+        for (int j = 0; j < KB - 1; j++) w[j] = ly[(k0 - 1 + j) * 64 + lane];
+#pragma unroll
+        for (int ub = 0; ub < TR; ub += KB) {
+#pragma unroll
+            for (int uu = 0; uu < KB; uu++) {
+                const int u = ub + uu;
+                w[(uu + KB - 1) % KB] = ly[(u + k0 + KB - 2) * 64 + lane];
+                double rv[N];
+#pragma unroll
+                for (int a = 0; a < N; a++) rv[a] = lrho[(a * TR + u) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < KB; j++) {
+                    const double yv = w[(uu + j) % KB];
+                    const double y2 = yv * yv;
+#pragma unroll
+                    for (int a = 0; a < N; a++) {
+                        g1[a][j] = __builtin_fma(rv[a], yv, g1[a][j]);
+                        g2[a][j] = __builtin_fma(rv[a], y2, g2[a][j]);
+                    }
+                }
+            }
+        }
+    }
+    if (kbi >= nkb) return;
+    const int NL = N * L;
+    double *out = partG + (size_t)blockIdx.x * 2 * NL;
+#pragma unroll
+    for (int a = 0; a < N; a++)
+#pragma unroll
+        for (int j = 0; j < KB; j++) {
+            double x1 = g1[a][j], x2 = g2[a][j];
+            for (int o = 32; o > 0; o >>= 1) { x1 += __shfl_xor(x1, o); x2 += __shfl_xor(x2, o); }
+            const int k = k0 + j;
+            if (lane == 0 && k <= L) {
+                out[a * L + (k - 1)] = x1;
+                out[NL + a * L + (k - 1)] = x2;
+            }
+        }
+}
+
 // virtual onsets t' = -j (rings already running at the first sample), the end-of-data correction
 // of G0 and pp = gamma[:,1] (baumwelch.jl:263).  One block.
 //   extra[0..NL)    = G0 contribution of virtual onsets  -  sum of rho over real onsets whose
@@ -739,16 +854,27 @@ int ring_estep_launch(RingDev *r, const double *d_y, double *d_stats, hipStream_
         constexpr int KB = gsum_kb<NN>();
         EParams<NN> ep = make_eparams<NN>(r);
         JParams<NN> jp = make_jparams_e<NN>(r);
-        { PROF(r, "k_fwd_chain", st); hipLaunchKernelGGL((k_fwd_chain<NN>), dim3(colgroups), dim3(64), 0, st, g, ep, r->yT, r->Rf,
-                           r->P, r->A0); }
-        { PROF(r, "k_bwd_chain", st); hipLaunchKernelGGL((k_bwd_chain<NN>), dim3(colgroups), dim3(64), 0, st, g, ep, r->yT, r->Rf,
-                           r->Q, r->B0, r->B0h); }
+        { PROF(r, "k_fb_chain", st); hipLaunchKernelGGL((k_fb_chain<NN>), dim3(2 * colgroups), dim3(64), 0, st, g, ep, r->yT, r->Rf,
+                           r->P, r->A0, r->Q, r->B0, r->B0h); }
         { PROF(r, "k_znorm", st); hipLaunchKernelGGL((k_znorm<NN>), dim3(colgroups, kZParts), dim3(64), 0, st, g, r->P, r->Q,
                            r->Zp); }
         { PROF(r, "k_post", st); hipLaunchKernelGGL((k_post<NN>), dim3(colgroups, (g.B + kPostRows - 1) / kPostRows), dim3(64), 0, st, g, jp, r->yT, r->Rf, r->P,
                            r->Q, r->A0, r->B0, r->Zp, r->Zc, r->rhoT, r->partS); }
-        { PROF(r, "k_gsum", st); hipLaunchKernelGGL((k_gsum<NN>), dim3(((colgroups + 7) / 8) * 8 * ((L + KB - 1) / KB)), dim3(64), 0, st, g, r->yT,
+        {
+            const int nkb = (L + KB - 1) / KB;
+            const size_t lds = ((size_t)NN * 16 * 64 + (size_t)(16 + nkb * KB - 1) * 64) * sizeof(double);
+            if (nkb <= 8 && NN * 16 * 64 % 512 == 0 && lds <= 150 * 1024 && g.B % 16 == 0) {
+                if (lds > 64 * 1024)
+                    HS_HIP(hipFuncSetAttribute((const void *)k_gsum_lds<NN>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                PROF(r, "k_gsum", st);
+                hipLaunchKernelGGL((k_gsum_lds<NN>), dim3(colgroups), dim3(512), lds, st, g, nkb, r->yT,
+                                   r->rhoT, r->partA);
+            } else {
+                { PROF(r, "k_gsum", st); hipLaunchKernelGGL((k_gsum<NN>), dim3(((colgroups + 7) / 8) * 8 * ((L + KB - 1) / KB)), dim3(64), 0, st, g, r->yT,
                            r->rhoT, r->partA); }
+            }
+        }
         { PROF(r, "k_fb_check", st); hipLaunchKernelGGL((k_fb_check<NN>), dim3(colgroups), dim3(64 * kChkParts), 0, st, g, 1e-9, r->P, r->Q,
                            r->A0, r->B0, r->B0h, r->Zc, r->rhoT, r->diag); }
         HS_HIP(hipGetLastError());
