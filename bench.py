@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--pooled", action="store_true", help="all-reduce E-step statistics (extension)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--neurons", type=int, default=4, help="templates (reference N); 4 = headline")
+    ap.add_argument("--states", type=int, default=60, help="states per template (reference K)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--halo", type=int, default=0)
     args = ap.parse_args()
@@ -123,9 +125,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # ---- workload: BASELINE config 2/3 model ----
-    N, K, T = 4, 60, args.samples
-    amps = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)]
-    pp = [0.003, 0.001, 0.002, 0.0015]
+    N, K, T = args.neurons, args.states, args.samples
+    base = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)]
+    amps = [(base[i % 4][0] * (1 + 0.13 * (i // 4)), base[i % 4][1] + 0.03 * (i // 4), base[i % 4][2])
+            for i in range(N)]
+    pp = [[0.003, 0.001, 0.002, 0.0015][i % 4] * (60.0 / K) for i in range(N)]
     sigma = 0.3
     temps = np.asfortranarray(np.stack([H.create_spike_template(K, *a) for a in amps], 1))
     seed = 1234 + rank
@@ -211,15 +215,16 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         res = {
-            "metric": "Msamples/sec (Viterbi + forward-backward), K=4 L=60 HMM",
+            "metric": "Msamples/sec (Viterbi + forward-backward), K=%d L=%d HMM" % (N, K),
             "value": world * T / (dt / args.steps) / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "K=4 L=60 HMM (reference N=4, K=60: 237 states), %d-sample single "
+            "config": {"workload": "K=%d L=%d HMM (reference N=%d, K=%d: %d states), %d-sample single "
                                    "channel per GPU: one Viterbi decode + one Baum-Welch E-step "
-                                   "(forward-backward + sufficient statistics + M-step finish)" % T,
+                                   "(forward-backward + sufficient statistics + M-step finish)"
+                                   % (N, K, N, K, S, T),
                        "channels": world, "samples_per_channel": T, "states": S,
                        "engine": "ring", "block": info["block"], "halo": info["halo"],
                        "chains": info["nchains"], "seed": 1234, "pooled_allreduce": bool(args.pooled)},
