@@ -36,6 +36,7 @@ def algorithmic_bytes(kernel, S, T):
     sweep: forward reads y (8) and writes alpha (8S); backward re-reads y and alpha (8S+8);
     Viterbi reads y (8), writes psi as Int16 per state (2S); backtrace reads >= 2 and writes x (2)."""
     per_sample = {
+        "k_vfb_chain": (2 * S + 8) + 2 * (8 * S + 8),  # Viterbi + forward + backward sweeps, one launch
         "k_fb_chain": 2 * (8 * S + 8),      # forward and backward sweeps in one launch
         "k_fwd_chain": 8 * S + 8,
         "k_bwd_chain": 8 * S + 8,
@@ -98,6 +99,8 @@ def main():
     ap.add_argument("--samples", type=int, default=10_000_000, help="samples per channel")
     ap.add_argument("--pooled", action="store_true", help="all-reduce E-step statistics (extension)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate", action="store_true",
+                    help="decode and E-step as two calls instead of hmmsort_plan_decode_estep")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--neurons", type=int, default=4, help="templates (reference N); 4 = headline")
     ap.add_argument("--states", type=int, default=60, help="states per template (reference K)")
@@ -151,8 +154,11 @@ def main():
 
     def step():
         plan.bind(dy, stream)              # transpose + ring-score pre-pass, once per step
-        plan.viterbi(dy, dx, dll, stream)
-        plan.estep(dy, stats, stream)
+        if args.separate:
+            plan.viterbi(dy, dx, dll, stream)
+            plan.estep(dy, stats, stream)
+        else:                              # same work, the three serial sweeps share one launch
+            plan.decode_estep(dy, dx, dll, stats, stream)
         if args.pooled and dist is not None:
             if args.backend == "nccl":
                 dist.all_reduce(stats)

@@ -59,6 +59,7 @@ SIGNATURES = {
     "hmmsort_plan_unbind": (_int, [_vp]),
     "hmmsort_plan_viterbi": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "hmmsort_plan_estep": (_int, [_vp, _vp, _vp, _vp]),
+    "hmmsort_plan_decode_estep": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "hmmsort_plan_stats_len": (_i64, [_vp]),
     "hmmsort_plan_mstep": (_int, [_vp, _vp, _vp, _vp]),
     "hmmsort_plan_diagnostics": (_int, [_vp, _vp, _pi64]),

@@ -235,6 +235,14 @@ int hmmsort_plan_viterbi(hmmsort_plan *p, const double *d_y, int16_t *d_x, doubl
     return generic_viterbi(p->gen, d_y, d_x, d_ll, st);
 }
 
+int hmmsort_plan_decode_estep(hmmsort_plan *p, const double *d_y, int16_t *d_x, double *d_ll,
+                              double *d_stats, void *stream)
+{
+    HS_CHECK(p && d_y && d_x && d_ll && d_stats, HMMSORT_EINVAL, "plan_decode_estep: null argument");
+    HS_CHECK(p->ring, HMMSORT_EUNSUP, "plan_decode_estep: needs the ring engine");
+    return ring_decode_estep_launch(p->ring, d_y, d_x, d_ll, d_stats, (hipStream_t)stream);
+}
+
 int64_t hmmsort_plan_stats_len(const hmmsort_plan *p)
 {
     if (!p || !p->ring) return 0;

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -83,7 +84,8 @@ struct RingDev {
     // device work arrays (allocated once per plan)
     double *yT = nullptr;         // B x ncol
     double *Rf = nullptr;         // N planes of B x ncol
-    double *P = nullptr;          // N planes of (H+B) x ncol   (Viterbi delay line / fwd lp)
+    double *P = nullptr;          // N planes of (H+B) x ncol   (forward lp)
+    double *Pv = nullptr;         // N planes of (H+B) x ncol   (Viterbi delay line)
     double *Q = nullptr;          // N planes of (L+B+H) x ncol (bwd ly)                 [E-step]
     double *A0 = nullptr;         // (1+B) x ncol fwd silent (row 0 = value before the chain)
     double *B0 = nullptr;         // B x ncol bwd silent
@@ -164,10 +166,46 @@ template <int N> constexpr int chain_unroll() { return N <= 4 ? 4 : (N <= 8 ? 2 
 // rows per thread of the pre-pass
 template <int N> constexpr int prepass_rows() { return N <= 8 ? 8 : 4; }
 
+template <int N>
+inline JParams<N> make_jparams(const RingDev *r)
+{
+    JParams<N> p;
+    p.c00 = r->ring.c00;
+    for (int a = 0; a < N; a++) {
+        p.c0[a] = r->ring.c0[a];
+        p.cend[a] = r->ring.cend[a];
+        for (int b = 0; b < N; b++) p.cx[a * N + b] = r->ring.cx[a * N + b];
+    }
+    p.mean0 = r->mean[0];
+    p.den = r->den;
+    p.A = r->A;
+    return p;
+}
+
+template <int N>
+inline EParams<N> make_eparams(const RingDev *r)
+{
+    EParams<N> p;
+    p.p00 = std::exp(r->ring.c00);
+    for (int a = 0; a < N; a++) {
+        p.p0[a] = std::exp(r->ring.c0[a]);
+        p.pend[a] = std::exp(r->ring.cend[a]);
+        for (int b = 0; b < N; b++) p.px[a * N + b] = (a == b) ? 0.0 : std::exp(r->ring.cx[a * N + b]);
+    }
+    p.mean0 = r->mean[0];
+    p.den = r->den;
+    return p;
+}
+
 // ring_viterbi.hip
 int ring_viterbi_launch(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st);
+int ring_viterbi_post(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st);
 // ring_estep.hip
 int ring_estep_launch(RingDev *r, const double *d_y, double *d_stats, hipStream_t st);
+int ring_estep_post(RingDev *r, const double *d_y, double *d_stats, hipStream_t st);
+// ring_fused.hip
+int ring_decode_estep_launch(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll, double *d_stats,
+                             hipStream_t st);
 int ring_mstep_launch(RingDev *r, const double *d_stats, double *d_out, hipStream_t st);
 // shared launch helpers (ring_engine.hip)
 int ring_launch_transpose_in(RingDev *r, const double *d_y, hipStream_t st);

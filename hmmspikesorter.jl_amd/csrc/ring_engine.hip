@@ -136,6 +136,7 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T, int64_t block_req,
     A(&r->yT, BC);
     A(&r->Rf, N * BC);
     A(&r->P, N * (int64_t)(g.H + g.B) * g.ncol);
+    A(&r->Pv, N * (int64_t)(g.H + g.B) * g.ncol);
     A(&r->Q, N * (int64_t)(g.L + g.B + g.H) * g.ncol);
     A(&r->A0, (int64_t)(1 + g.B) * g.ncol);
     A(&r->B0, BC);
@@ -162,6 +163,7 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T, int64_t block_req,
         // test aid: fill the work arrays with NaN bit patterns so that a kernel reading an
         // element nobody wrote shows up as NaN instead of depending on stale memory
         (void)hipMemset(r->P, 0xFF, N * (int64_t)(g.H + g.B) * g.ncol * 8);
+        (void)hipMemset(r->Pv, 0xFF, N * (int64_t)(g.H + g.B) * g.ncol * 8);
         (void)hipMemset(r->Q, 0xFF, N * (int64_t)(g.L + g.B + g.H) * g.ncol * 8);
         (void)hipMemset(r->A0, 0xFF, (int64_t)(1 + g.B) * g.ncol * 8);
         (void)hipMemset(r->B0, 0xFF, BC * 8);
@@ -184,7 +186,7 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T, int64_t block_req,
 void ring_destroy(RingDev *r)
 {
     if (!r) return;
-    void *ptrs[] = {r->d_mean, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->yT, r->Rf, r->P, r->Q, r->A0,
+    void *ptrs[] = {r->d_mean, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->yT, r->Rf, r->P, r->Pv, r->Q, r->A0,
                     r->B0, r->psi, r->psiH, r->D0end, r->D0pre, r->bstate, r->redo, r->xT, r->final_state,
                     r->part, r->Zc, r->Zp, r->B0h, r->partA, r->partS, r->rhoT, r->extra, r->pp, r->diag};
     for (void *p : ptrs)

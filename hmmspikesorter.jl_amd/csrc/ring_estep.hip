@@ -20,253 +20,11 @@
 #include <type_traits>
 
 #include "fastmath.h"
+#include "ring_chain_bodies.h"
 #include "ring_common.h"
 
 namespace hmmsort {
 
-template <int N>
-struct ChainIn {
-    double y;
-    double R[N];
-    double X[N];
-};
-
-// ------------------------------------------------------------------------------------------
-// forward chains (baumwelch.jl:25-51).  Same skeleton as k_vit_chain; max -> log-sum-exp.
-// The N+1 exponentials fexp(value - m) are shared by all N+1 junction sums.
-// ------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void fwd_chain_body(int bx, const RingGeom &g, const EParams<N> &ep,
-                                               const double *__restrict__ yT,
-                                               const double *__restrict__ Rf,
-                                               double *__restrict__ P, double *__restrict__ A0)
-{
-    constexpr int U = chain_unroll<N>();
-    const int c = bx * 64 + threadIdx.x;
-    const int B = g.B, H = g.H, L = g.L, ncol = g.ncol;
-    const bool active = c < g.nch;
-    const int64_t tc = (int64_t)c * B;
-    const int nc = active ? (int)((g.T - tc) < B ? (g.T - tc) : B) : 0;
-    const int s0 = (c == 0) ? 0 : -H;
-    const int64_t planeR = (int64_t)B * ncol, planeP = (int64_t)(H + B) * ncol;
-
-    auto load = [&](ChainIn<N>(&d)[U], int sb) {  // unconditional loads, see k_vit_chain
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int s = sb + u;
-            const bool live = active && s >= s0 && s < nc;
-            const int sc = live ? s : 0;
-            const int cc = active ? c : 0;
-            const int64_t off = (sc >= 0) ? (int64_t)sc * ncol + cc : (int64_t)(B + sc) * ncol + (cc > 0 ? cc - 1 : 0);
-            const bool hasx = live && (s - L >= -H);
-            const int64_t offp = (int64_t)(hasx ? H + s - L : H) * ncol + cc;
-            const double yv = yT[off];
-            double rv[N], xv[N];
-#pragma unroll
-            for (int a = 0; a < N; a++) rv[a] = Rf[a * planeR + off];
-#pragma unroll
-            for (int a = 0; a < N; a++) xv[a] = P[a * planeP + offp];
-            d[u].y = live ? yv : 0.0;
-#pragma unroll
-            for (int a = 0; a < N; a++) {
-                d[u].R[a] = live ? rv[a] : 0.0;
-                d[u].X[a] = hasx ? xv[a] : -INFINITY;
-            }
-        }
-    };
-
-    ChainIn<N> bufA[U], bufB[U];
-    double la0 = 0.0;
-    auto run = [&](ChainIn<N>(&cur)[U], int sb) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int s = sb + u;
-            const bool live = active && s >= s0 && s < nc;
-            if (live) {
-                double Pn[N];
-                const double d = cur[u].y - ep.mean0;
-                const double q0 = -(d * d) / ep.den;
-                if (s == s0) {
-                    if (c == 0) {  // baumwelch.jl:36: first column = emission only, every state
-                        la0 = q0;
-#pragma unroll
-                        for (int a = 0; a < N; a++) Pn[a] = cur[u].R[a];
-                    } else {       // warm-up start: silent, rings empty
-                        la0 = 0.0;
-#pragma unroll
-                        for (int a = 0; a < N; a++) Pn[a] = -INFINITY;
-                    }
-                } else {
-                    double m = la0;
-#pragma unroll
-                    for (int a = 0; a < N; a++) m = fmax(m, cur[u].X[a]);
-                    double ev[N + 1];  // exp(value - m), shared by all junction sums
-                    ev[N] = la0 - m;
-#pragma unroll
-                    for (int a = 0; a < N; a++) ev[a] = cur[u].X[a] - m;
-                    fexp_n<N + 1>(ev);
-                    const double e0 = ev[N];
-                    double sv[N + 1];  // the N+1 junction sums
-                    sv[N] = e0 * ep.p00;
-#pragma unroll
-                    for (int a = 0; a < N; a++) sv[N] = __builtin_fma(ev[a], ep.pend[a], sv[N]);
-#pragma unroll
-                    for (int a = 0; a < N; a++) {
-                        double su = e0 * ep.p0[a];
-#pragma unroll
-                        for (int b = 0; b < N; b++)
-                            if (b != a) su = __builtin_fma(ev[b], ep.px[b * N + a], su);
-                        sv[a] = su;
-                    }
-                    flog_n<N + 1>(sv);
-#pragma unroll
-                    for (int a = 0; a < N; a++) Pn[a] = (m + sv[a]) + cur[u].R[a];
-                    la0 = (m + sv[N]) + q0;
-                }
-                const int64_t offp = (int64_t)(H + s) * ncol + c;
-#pragma unroll
-                for (int a = 0; a < N; a++) P[a * planeP + offp] = Pn[a];
-                if (s >= -1) A0[(int64_t)(1 + s) * ncol + c] = la0;
-            }
-        }
-    };
-    load(bufA, -H);
-    for (int sb = -H; sb < B; sb += 2 * U) {  // ping-pong, no register copies
-        load(bufB, sb + U);
-        run(bufA, sb);
-        if (sb + 2 * U < B) load(bufA, sb + 2 * U);
-        run(bufB, sb + U);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// backward chains (baumwelch.jl:73-98).  Chain c runs from te = min(tc+nc+H, T)-1 down to tc.
-// beta = 0 for every state at te: the reference's terminal condition when te is the last sample
-// (:80), an arbitrary warm-up start otherwise.  ly_a(t') for rings that have not finished by te
-// is 0 for the same reason.
-// Q row (L + s') holds ly_a(tc + s'), s' in [-(L-1), B+H).
-// ------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void bwd_chain_body(int bx, const RingGeom &g, const EParams<N> &ep,
-                                               const double *__restrict__ yT,
-                                               const double *__restrict__ Rf,
-                                               double *__restrict__ Q, double *__restrict__ B0,
-                                               double *__restrict__ B0h)
-{
-    constexpr int U = chain_unroll<N>();
-    const int c = bx * 64 + threadIdx.x;
-    const int B = g.B, H = g.H, L = g.L, ncol = g.ncol;
-    const bool active = c < g.nch;
-    const int64_t tc = (int64_t)c * B;
-    const int nc = active ? (int)((g.T - tc) < B ? (g.T - tc) : B) : 0;
-    int64_t te = tc + nc + H;
-    if (te > g.T) te = g.T;
-    const int se = active ? (int)(te - 1 - tc) : -1;
-    const int64_t planeR = (int64_t)B * ncol, planeQ = (int64_t)(L + B + H) * ncol;
-
-    // inputs of step s (computing time t = tc+s from t+1): y, Rf and ly at time t+1
-    auto load = [&](ChainIn<N>(&d)[U], int sb) {  // unconditional loads, see k_vit_chain
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int s = sb - u;
-            const bool live = active && s < se && s >= 0;
-            const int s1 = live ? s + 1 : 0;
-            const int cc = active ? c : 0;
-            const int64_t off = (s1 < B) ? (int64_t)s1 * ncol + cc : (int64_t)(s1 - B) * ncol + cc + 1;
-            const bool hasq = live && (s + L <= se);  // the ring started at t+1 ends inside the range
-            const int64_t offq = (int64_t)(hasq ? L + s1 : L) * ncol + cc;
-            const double yv = yT[off];
-            double rv[N], xv[N];
-#pragma unroll
-            for (int a = 0; a < N; a++) rv[a] = Rf[a * planeR + off];
-#pragma unroll
-            for (int a = 0; a < N; a++) xv[a] = Q[a * planeQ + offq];
-            d[u].y = live ? yv : 0.0;
-#pragma unroll
-            for (int a = 0; a < N; a++) {
-                d[u].R[a] = live ? rv[a] : 0.0;
-                d[u].X[a] = hasq ? xv[a] : 0.0;
-            }
-        }
-    };
-
-    ChainIn<N> bufA[U], bufB[U];
-    double lb0 = 0.0;
-    const int stop = B + H - 1;
-    auto run = [&](ChainIn<N>(&cur)[U], int sb) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int s = sb - u;
-            if (active && s <= se && s >= 0) {
-                double Yn[N];
-                if (s == se) {
-                    lb0 = 0.0;
-#pragma unroll
-                    for (int a = 0; a < N; a++) Yn[a] = 0.0;
-                    // onsets whose ring runs past te: ly = 0 (rows the sweep below never writes,
-                    // read by the statistics kernels when te is the end of the data)
-                    for (int i = 2; i <= L; i++) {
-                        const int64_t o = (int64_t)(s + i) * ncol + c;
-#pragma unroll
-                        for (int a = 0; a < N; a++) Q[a * planeQ + o] = 0.0;
-                    }
-                } else {
-                    const double d = cur[u].y - ep.mean0;
-                    const double v0 = lb0 - (d * d) / ep.den;
-                    double lw[N];
-                    double m = v0;
-#pragma unroll
-                    for (int a = 0; a < N; a++) {
-                        lw[a] = cur[u].R[a] + cur[u].X[a];
-                        m = fmax(m, lw[a]);
-                    }
-                    double ev[N + 1];
-                    ev[N] = v0 - m;
-#pragma unroll
-                    for (int a = 0; a < N; a++) ev[a] = lw[a] - m;
-                    fexp_n<N + 1>(ev);
-                    const double E0 = ev[N];
-                    double sv[N + 1];
-                    sv[N] = E0 * ep.p00;
-#pragma unroll
-                    for (int a = 0; a < N; a++) sv[N] = __builtin_fma(ev[a], ep.p0[a], sv[N]);
-#pragma unroll
-                    for (int a = 0; a < N; a++) {
-                        double su = E0 * ep.pend[a];
-#pragma unroll
-                        for (int b = 0; b < N; b++)
-                            if (b != a) su = __builtin_fma(ev[b], ep.px[a * N + b], su);
-                        sv[a] = su;
-                    }
-                    flog_n<N + 1>(sv);
-#pragma unroll
-                    for (int a = 0; a < N; a++) Yn[a] = m + sv[a];
-                    lb0 = m + sv[N];
-                }
-                const int64_t offq = (int64_t)(s + 1) * ncol + c;  // onset index s-L+1 -> row s+1
-#pragma unroll
-                for (int a = 0; a < N; a++) Q[a * planeQ + offq] = Yn[a];
-                if (s < nc) B0[(int64_t)s * ncol + c] = lb0;
-                if (s == nc) B0h[c] = lb0;
-            }
-        }
-    };
-    load(bufA, stop);
-    for (int sb = stop; sb >= 0; sb -= 2 * U) {  // ping-pong, no register copies
-        load(bufB, sb - U);
-        run(bufA, sb);
-        if (sb - 2 * U >= 0) load(bufA, sb - 2 * U);
-        run(bufB, sb - U);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_post: per-chain normaliser + posteriors.  Lane = chain.
-//   Zc = log sum over ALL states of alpha*beta at t* = tc + L - 1
-//        silent: la0(t*) + lb0(t*);  ring state (a,k): lp_a(t') + ly_a(t'), t' in [tc, t*];
-//   rho_a(t') = fexp(lp_a + ly_a - Zc)  -> rhoT (transposed layout, zero where there is no onset);
-//   scalar sums: gamma_t(silent) (all t; t < T-1; times y^2), xi_a, sum_t' rho_a(t').
-// ------------------------------------------------------------------------------------------
 // Forward and backward sweeps are independent until the statistics; one launch runs both, the
 // forward chains on the even blocks and the backward chains on the odd ones, so 2 x (chains/64)
 // wavefronts share the 1024 SIMDs instead of running half-empty one after the other.
@@ -809,53 +567,38 @@ __global__ __launch_bounds__(256) void k_mstep(int N, int L, const double *__res
     }
 }
 
-template <int N>
-static EParams<N> make_eparams(const RingDev *r)
-{
-    EParams<N> p;
-    p.p00 = std::exp(r->ring.c00);
-    for (int a = 0; a < N; a++) {
-        p.p0[a] = std::exp(r->ring.c0[a]);
-        p.pend[a] = std::exp(r->ring.cend[a]);
-        for (int b = 0; b < N; b++) p.px[a * N + b] = (a == b) ? 0.0 : std::exp(r->ring.cx[a * N + b]);
-    }
-    p.mean0 = r->mean[0];
-    p.den = r->den;
-    return p;
-}
-
-template <int N>
-static JParams<N> make_jparams_e(const RingDev *r)
-{
-    JParams<N> p;
-    p.c00 = r->ring.c00;
-    for (int a = 0; a < N; a++) {
-        p.c0[a] = r->ring.c0[a];
-        p.cend[a] = r->ring.cend[a];
-        for (int b = 0; b < N; b++) p.cx[a * N + b] = r->ring.cx[a * N + b];
-    }
-    p.mean0 = r->mean[0];
-    p.den = r->den;
-    p.A = r->A;
-    return p;
-}
-
 int ring_estep_launch(RingDev *r, const double *d_y, double *d_stats, hipStream_t st)
 {
     const RingGeom &g = r->g;
-    const int N = g.N, L = g.L, NL = N * L;
     int rc;
     HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
     if ((rc = ring_prepare(r, d_y, st))) return rc;
     if ((rc = ring_launch_virtual(r, d_y, r->P, (int64_t)(g.H + g.B) * g.ncol, st))) return rc;
     const int colgroups = g.ncol / 64;
+    rc = dispatch_N(g.N, [&](auto n) {
+        constexpr int NN = decltype(n)::value;
+        EParams<NN> ep = make_eparams<NN>(r);
+        { PROF(r, "k_fb_chain", st); hipLaunchKernelGGL((k_fb_chain<NN>), dim3(2 * colgroups), dim3(64), 0, st, g, ep, r->yT, r->Rf,
+                           r->P, r->A0, r->Q, r->B0, r->B0h); }
+        HS_HIP(hipGetLastError());
+        return HMMSORT_OK;
+    });
+    if (rc) return rc;
+    return ring_estep_post(r, d_y, d_stats, st);
+}
+
+// everything after the forward/backward sweeps: normaliser, posteriors, statistics, certificate
+int ring_estep_post(RingDev *r, const double *d_y, double *d_stats, hipStream_t st)
+{
+    const RingGeom &g = r->g;
+    const int N = g.N, L = g.L, NL = N * L;
+    int rc;
+    const int colgroups = g.ncol / 64;
     rc = dispatch_N(N, [&](auto n) {
         constexpr int NN = decltype(n)::value;
         constexpr int KB = gsum_kb<NN>();
-        EParams<NN> ep = make_eparams<NN>(r);
-        JParams<NN> jp = make_jparams_e<NN>(r);
-        { PROF(r, "k_fb_chain", st); hipLaunchKernelGGL((k_fb_chain<NN>), dim3(2 * colgroups), dim3(64), 0, st, g, ep, r->yT, r->Rf,
-                           r->P, r->A0, r->Q, r->B0, r->B0h); }
+        JParams<NN> jp = make_jparams<NN>(r);
+
         { PROF(r, "k_znorm", st); hipLaunchKernelGGL((k_znorm<NN>), dim3(colgroups, kZParts), dim3(64), 0, st, g, r->P, r->Q,
                            r->Zp); }
         { PROF(r, "k_post", st); hipLaunchKernelGGL((k_post<NN>), dim3(colgroups, (g.B + kPostRows - 1) / kPostRows), dim3(64), 0, st, g, jp, r->yT, r->Rf, r->P,

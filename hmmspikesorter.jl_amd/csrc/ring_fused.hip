@@ -1,0 +1,55 @@
+// Ring engine, part 4: one decode + one E-step of the SAME bound signal and model in a single
+// call.  The three serial sweeps (Viterbi, forward, backward) are independent of each other, so
+// they share one launch: block 3i runs the Viterbi chains of column group i, block 3i+1 the
+// forward chains, block 3i+2 the backward chains.  Three times as many wavefronts are resident,
+// which is what a lane-per-chain design needs when a single recording supplies only ~600 of them.
+// Results are identical to hmmsort_plan_viterbi followed by hmmsort_plan_estep.
+#include <type_traits>
+
+#include "ring_chain_bodies.h"
+#include "ring_common.h"
+
+namespace hmmsort {
+
+template <int N>
+__global__ __launch_bounds__(64) void k_vfb_chain(RingGeom g, JParams<N> jp, EParams<N> ep,
+                                                  const double *__restrict__ yT,
+                                                  const double *__restrict__ Rf,
+                                                  double *__restrict__ Pv, uint32_t *__restrict__ psi,
+                                                  double *__restrict__ D0pre, double *__restrict__ D0end,
+                                                  double *__restrict__ P, double *__restrict__ A0,
+                                                  double *__restrict__ Q, double *__restrict__ B0,
+                                                  double *__restrict__ B0h)
+{
+    const int bx = blockIdx.x / 3, role = blockIdx.x % 3;
+    if (role == 0) vit_chain_body<N>(bx, g, jp, yT, Rf, Pv, psi, D0pre, D0end);
+    else if (role == 1) fwd_chain_body<N>(bx, g, ep, yT, Rf, P, A0);
+    else bwd_chain_body<N>(bx, g, ep, yT, Rf, Q, B0, B0h);
+}
+
+int ring_decode_estep_launch(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll, double *d_stats,
+                             hipStream_t st)
+{
+    const RingGeom &g = r->g;
+    int rc;
+    HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
+    if ((rc = ring_prepare(r, d_y, st))) return rc;
+    const int64_t planeP = (int64_t)(g.H + g.B) * g.ncol;
+    if ((rc = ring_launch_virtual(r, d_y, r->Pv, planeP, st))) return rc;
+    if ((rc = ring_launch_virtual(r, d_y, r->P, planeP, st))) return rc;
+    rc = dispatch_N(g.N, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        JParams<N> jp = make_jparams<N>(r);
+        EParams<N> ep = make_eparams<N>(r);
+        { PROF(r, "k_vfb_chain", st);
+          hipLaunchKernelGGL((k_vfb_chain<N>), dim3(3 * (g.ncol / 64)), dim3(64), 0, st, g, jp, ep, r->yT, r->Rf,
+                             r->Pv, r->psi, r->D0pre, r->D0end, r->P, r->A0, r->Q, r->B0, r->B0h); }
+        HS_HIP(hipGetLastError());
+        return HMMSORT_OK;
+    });
+    if (rc) return rc;
+    if ((rc = ring_viterbi_post(r, d_y, d_x, d_ll, st))) return rc;
+    return ring_estep_post(r, d_y, d_stats, st);
+}
+
+}  // namespace hmmsort

@@ -18,16 +18,10 @@
 #include <cmath>
 #include <type_traits>
 
+#include "ring_chain_bodies.h"
 #include "ring_common.h"
 
 namespace hmmsort {
-
-template <int N>
-struct VitIn {
-    double y;
-    double R[N];
-    double X[N];
-};
 
 // One lane = one chain.  grid = ncol/64 blocks of 64 threads.
 template <int N>
@@ -39,118 +33,7 @@ __global__ __launch_bounds__(64) void k_vit_chain(RingGeom g, JParams<N> jp,
                                                   double *__restrict__ D0pre,
                                                   double *__restrict__ D0end)
 {
-    constexpr int U = chain_unroll<N>();
-    constexpr int BITS = psi_bits_c(N), EPW = psi_epw_c(N), W = psi_words_c(N);
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    const int B = g.B, H = g.H, L = g.L, ncol = g.ncol;
-    const bool active = c < g.nch;
-    const int64_t tc = (int64_t)c * B;
-    const int nc = active ? (int)((g.T - tc) < B ? (g.T - tc) : B) : 0;
-    const int s0 = (c == 0) ? 0 : -H;
-    const int64_t planeR = (int64_t)B * ncol, planeP = (int64_t)(H + B) * ncol;
-    const int64_t planePsi = (int64_t)B * ncol;
-    // Loads are unconditional (idle lanes read a clamped, valid address and discard the value):
-    // straight-line loads let the compiler count vmcnt exactly, so a batch only waits for its
-    // own data while the next batch's loads stay in flight.
-    auto load = [&](VitIn<N>(&d)[U], int sb) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int s = sb + u;
-            const bool live = active && s >= s0 && s < nc;
-            const int sc = live ? s : 0;             // clamped step
-            const int cc = active ? c : 0;           // clamped column
-            const int64_t off = (sc >= 0) ? (int64_t)sc * ncol + cc : (int64_t)(B + sc) * ncol + (cc > 0 ? cc - 1 : 0);
-            const bool hasx = live && (s - L >= -H);
-            const int64_t offp = (int64_t)(hasx ? H + s - L : H) * ncol + cc;
-            const double yv = yT[off];
-            double rv[N], xv[N];
-#pragma unroll
-            for (int a = 0; a < N; a++) rv[a] = Rf[a * planeR + off];
-#pragma unroll
-            for (int a = 0; a < N; a++) xv[a] = P[a * planeP + offp];
-            d[u].y = live ? yv : 0.0;
-#pragma unroll
-            for (int a = 0; a < N; a++) {
-                d[u].R[a] = live ? rv[a] : 0.0;
-                d[u].X[a] = hasx ? xv[a] : -INFINITY;
-            }
-        }
-    };
-
-    VitIn<N> bufA[U], bufB[U];
-    double D0 = 0.0;
-    const int sfirst = -H;  // wave-uniform loop start (chain 0 idles through the warm-up steps)
-    auto run = [&](VitIn<N>(&cur)[U], int sb) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int s = sb + u;
-            const bool live = active && s >= s0 && s < nc;
-            if (live) {
-                double Pn[N];
-                uint32_t pw[W];
-#pragma unroll
-                for (int w = 0; w < W; w++) pw[w] = 0u;
-                if (s == s0) {
-                    // first sample of the chain: chain 0 = the reference's first column
-                    // (viterbi.jl:55-63: emission only, T1[1,1] = 0); others = "silent, rings
-                    // empty" warm-up start
-                    if (c == 0) {
-                        D0 = -jp.A;
-#pragma unroll
-                        for (int a = 0; a < N; a++) Pn[a] = cur[u].R[a];
-                    } else {
-                        D0 = 0.0;
-#pragma unroll
-                        for (int a = 0; a < N; a++) Pn[a] = -INFINITY;
-                    }
-                } else {
-                    double best0 = D0 + jp.c00;
-                    int p0 = 0;
-#pragma unroll
-                    for (int a = 0; a < N; a++) {
-                        const double v = cur[u].X[a] + jp.cend[a];
-                        if (v > best0) { best0 = v; p0 = a + 1; }
-                    }
-                    pw[0] = (uint32_t)p0;
-#pragma unroll
-                    for (int a = 0; a < N; a++) {
-                        double ua = D0 + jp.c0[a];
-                        int pa = 0;
-#pragma unroll
-                        for (int b = 0; b < N; b++) {
-                            if (b == a) continue;
-                            const double v = cur[u].X[b] + jp.cx[b * N + a];
-                            if (v > ua) { ua = v; pa = b + 1; }
-                        }
-                        Pn[a] = ua + cur[u].R[a];
-                        pw[(a + 1) / EPW] |= (uint32_t)pa << (((a + 1) % EPW) * BITS);
-                    }
-                    const double d = cur[u].y - jp.mean0;
-                    D0 = best0 - (d * d) / jp.den;
-                }
-                const int64_t offp = (int64_t)(H + s) * ncol + c;
-#pragma unroll
-                for (int a = 0; a < N; a++) P[a * planeP + offp] = Pn[a];
-                if (s >= 0) {
-                    const int64_t o = (int64_t)s * ncol + c;
-#pragma unroll
-                    for (int w = 0; w < W; w++) psi[w * planePsi + o] = pw[w];
-                } else if (s == -1) {
-                    D0pre[c] = D0;  // delta(silent) one sample before the chain, warm-up frame
-                }
-                if (s == nc - 1) D0end[c] = D0;
-            }
-        }
-    };
-    // two batches per iteration, ping-pong: a batch's inputs are fetched while the previous
-    // batch computes, with no register copies (H and B are multiples of 64, hence of 2U)
-    load(bufA, sfirst);
-    for (int sb = sfirst; sb < B; sb += 2 * U) {
-        load(bufB, sb + U);
-        run(bufA, sb);
-        if (sb + 2 * U < B) load(bufA, sb + 2 * U);
-        run(bufB, sb + U);
-    }
+    vit_chain_body<N>(blockIdx.x, g, jp, yT, Rf, P, psi, D0pre, D0end);
 }
 
 // Final state = argmax over all S states at the last sample, first maximum in state order
@@ -476,40 +359,32 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__
     if (threadIdx.x == 0) *out = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <int N>
-static JParams<N> make_jparams(const RingDev *r)
-{
-    JParams<N> p;
-    p.c00 = r->ring.c00;
-    for (int a = 0; a < N; a++) {
-        p.c0[a] = r->ring.c0[a];
-        p.cend[a] = r->ring.cend[a];
-        for (int b = 0; b < N; b++) p.cx[a * N + b] = r->ring.cx[a * N + b];
-    }
-    p.mean0 = r->mean[0];
-    p.den = r->den;
-    p.A = r->A;
-    return p;
-}
-
 int ring_viterbi_launch(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st)
 {
     const RingGeom &g = r->g;
     int rc;
     HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
-    HS_HIP(hipMemsetAsync(r->redo, 0, sizeof(int32_t), st));
     if ((rc = ring_prepare(r, d_y, st))) return rc;
-    if ((rc = ring_launch_virtual(r, d_y, r->P, (int64_t)(g.H + g.B) * g.ncol, st))) return rc;
+    if ((rc = ring_launch_virtual(r, d_y, r->Pv, (int64_t)(g.H + g.B) * g.ncol, st))) return rc;
     rc = dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
         JParams<N> jp = make_jparams<N>(r);
         { PROF(r, "k_vit_chain", st); hipLaunchKernelGGL((k_vit_chain<N>), dim3(g.ncol / 64), dim3(64), 0, st, g, jp, r->yT,
-                           r->Rf, r->P, r->psi, r->D0pre, r->D0end); }
+                           r->Rf, r->Pv, r->psi, r->D0pre, r->D0end); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
     });
     if (rc) return rc;
-    { PROF(r, "k_vit_tail", st); hipLaunchKernelGGL(k_vit_tail, dim3(1), dim3(64), 0, st, g, r->P, r->D0end, r->final_state); }
+    return ring_viterbi_post(r, d_y, d_x, d_ll, st);
+}
+
+// everything after the chain sweep: final state, backtrace + stitch, boundary certificate, x, ll
+int ring_viterbi_post(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st)
+{
+    const RingGeom &g = r->g;
+    int rc;
+    HS_HIP(hipMemsetAsync(r->redo, 0, sizeof(int32_t), st));
+    { PROF(r, "k_vit_tail", st); hipLaunchKernelGGL(k_vit_tail, dim3(1), dim3(64), 0, st, g, r->Pv, r->D0end, r->final_state); }
     rc = dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
         { PROF(r, "k_vit_backtrace", st); hipLaunchKernelGGL((k_vit_backtrace<N>), dim3(g.ncol / 64), dim3(64), 0, st, g, r->psi,
@@ -533,7 +408,7 @@ int ring_viterbi_launch(RingDev *r, const double *d_y, int16_t *d_x, double *d_l
         }
         PROF(r, "k_halo_check", st);
         hipLaunchKernelGGL(k_halo_check, dim3(g.ncol / 64), dim3(64 * kVChkParts), (size_t)g.L * 64 * sizeof(double), st,
-                           g, ka, 1e-6, r->yT, r->P, r->D0pre, r->D0end, r->diag);
+                           g, ka, 1e-6, r->yT, r->Pv, r->D0pre, r->D0end, r->diag);
     }
     { PROF(r, "k_transpose_x", st); hipLaunchKernelGGL(k_transpose_x, dim3(g.B / 64, g.ncol / 64), dim3(256), 0, st, r->xT, g.T,
                        g.B, g.ncol, d_x); }

@@ -70,6 +70,11 @@ class Plan:
     def estep(self, d_y, d_stats, stream=0):
         check(lib().hmmsort_plan_estep(self._h, _dptr(d_y), _dptr(d_stats), C.c_void_p(stream)))
 
+    def decode_estep(self, d_y, d_x, d_ll, d_stats, stream=0):
+        """viterbi + estep of the same signal/model with the three sweeps sharing one launch"""
+        check(lib().hmmsort_plan_decode_estep(self._h, _dptr(d_y), _dptr(d_x), _dptr(d_ll),
+                                              _dptr(d_stats), C.c_void_p(stream)))
+
     def mstep(self, d_stats, d_out, stream=0):
         check(lib().hmmsort_plan_mstep(self._h, _dptr(d_stats), _dptr(d_out), C.c_void_p(stream)))
 

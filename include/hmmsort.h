@@ -169,6 +169,11 @@ int hmmsort_plan_viterbi(hmmsort_plan *plan, const double *d_y, int16_t *d_x, do
  * plain sum over time, so shards of one recording / pooled channels combine by a SUM
  * all-reduce (RCCL) before the M-step. */
 int hmmsort_plan_estep(hmmsort_plan *plan, const double *d_y, double *d_stats, void *stream);
+/* hmmsort_plan_viterbi + hmmsort_plan_estep of the same signal and model in one call: the three
+ * serial sweeps (Viterbi, forward, backward) are independent and share one launch, so three times
+ * as many wavefronts are resident.  Same results as the two separate calls.  Ring engine only. */
+int hmmsort_plan_decode_estep(hmmsort_plan *plan, const double *d_y, int16_t *d_x, double *d_ll,
+                              double *d_stats, void *stream);
 int64_t hmmsort_plan_stats_len(const hmmsort_plan *plan);
 /* M-step finish from (all-reduced) statistics, on device: d_out receives
  * [mu (K*N) | sigma (1) | lp_new (N) | pp (S)] = K*N + 1 + N + S doubles. */

@@ -80,6 +80,18 @@ def test_estep_properties_at_10M(H, big):
     plan.unbind()
     torch.cuda.synchronize()
     assert torch.equal(stats, stats3)
+    # decode + E-step in one call (three sweeps in one launch) == the two separate calls
+    dx1 = torch.zeros(T, dtype=torch.int16, device="cuda")
+    dx2 = torch.zeros_like(dx1)
+    ll1 = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ll2 = torch.zeros_like(ll1)
+    stats4 = torch.zeros_like(stats)
+    plan.viterbi(dy, dx1, ll1, st)
+    plan.decode_estep(dy, dx2, ll2, stats4, st)
+    d2 = plan.diagnostics(st)
+    torch.cuda.synchronize()
+    assert torch.equal(dx1, dx2) and torch.equal(ll1, ll2) and torch.equal(stats, stats4)
+    assert d2[0] == 0 and d2[3] == 0 and d2[5] == 0
     plan.close()
 
 
