@@ -21,7 +21,12 @@ __global__ __launch_bounds__(64) void k_vfb_chain(RingGeom g, JParams<N> jp, EPa
                                                   double *__restrict__ Q, double *__restrict__ B0,
                                                   double *__restrict__ B0h)
 {
-    const int bx = blockIdx.x / 3, role = blockIdx.x % 3;
+    // XCD-aware: blocks b and b+8 share an XCD (and its L2).  The three roles of column group i
+    // get slots 24*(i/8) + 8*role + i%8, i.e. the same XCD, so the y / ring-score rows the Viterbi
+    // and forward chains read at the same step come from HBM once.
+    const int grp = blockIdx.x / 24, rem = blockIdx.x % 24;
+    const int role = rem >> 3, bx = grp * 8 + (rem & 7);
+    if (bx * 64 >= g.ncol) return;
     if (role == 0) vit_chain_body<N>(bx, g, jp, yT, Rf, Pv, psi, D0pre, D0end);
     else if (role == 1) fwd_chain_body<N>(bx, g, ep, yT, Rf, P, A0);
     else bwd_chain_body<N>(bx, g, ep, yT, Rf, Q, B0, B0h);
@@ -42,7 +47,7 @@ int ring_decode_estep_launch(RingDev *r, const double *d_y, int16_t *d_x, double
         JParams<N> jp = make_jparams<N>(r);
         EParams<N> ep = make_eparams<N>(r);
         { PROF(r, "k_vfb_chain", st);
-          hipLaunchKernelGGL((k_vfb_chain<N>), dim3(3 * (g.ncol / 64)), dim3(64), 0, st, g, jp, ep, r->yT, r->Rf,
+          hipLaunchKernelGGL((k_vfb_chain<N>), dim3(24 * ((g.ncol / 64 + 7) / 8)), dim3(64), 0, st, g, jp, ep, r->yT, r->Rf,
                              r->Pv, r->psi, r->D0pre, r->D0end, r->P, r->A0, r->Q, r->B0, r->B0h); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
