@@ -61,6 +61,7 @@ SIGNATURES = {
     "hmmsort_plan_estep": (_int, [_vp, _vp, _vp, _vp]),
     "hmmsort_plan_decode_estep": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "hmmsort_plan_stats_len": (_i64, [_vp]),
+    "hmmsort_plan_set_shard": (_int, [_vp, _i64, _i64, _int, _int]),
     "hmmsort_plan_mstep": (_int, [_vp, _vp, _vp, _vp]),
     "hmmsort_plan_diagnostics": (_int, [_vp, _vp, _pi64]),
     "hmmsort_plan_profile": (_int, [_vp, _int]),

@@ -243,6 +243,20 @@ int hmmsort_plan_decode_estep(hmmsort_plan *p, const double *d_y, int16_t *d_x, 
     return ring_decode_estep_launch(p->ring, d_y, d_x, d_ll, d_stats, (hipStream_t)stream);
 }
 
+int hmmsort_plan_set_shard(hmmsort_plan *p, int64_t own_lo, int64_t own_hi, int first, int last)
+{
+    HS_CHECK(p, HMMSORT_EINVAL, "plan_set_shard: null plan");
+    HS_CHECK(p->ring, HMMSORT_EUNSUP, "plan_set_shard: needs the ring engine");
+    HS_CHECK(own_lo >= 0 && own_lo <= own_hi && own_hi <= p->T, HMMSORT_EINVAL,
+             "plan_set_shard: owned range [%lld, %lld) outside [0, %lld]", (long long)own_lo,
+             (long long)own_hi, (long long)p->T);
+    HS_CHECK((!first || own_lo == 0) && (!last || own_hi == p->T), HMMSORT_EINVAL,
+             "plan_set_shard: a first/last shard must own its first/last sample");
+    p->ring->g.own_lo = own_lo; p->ring->g.own_hi = own_hi;
+    p->ring->g.first = first != 0; p->ring->g.last = last != 0;
+    return HMMSORT_OK;
+}
+
 int64_t hmmsort_plan_stats_len(const hmmsort_plan *p)
 {
     if (!p || !p->ring) return 0;

@@ -35,6 +35,10 @@ struct RingGeom {
     int ncol;      // columns of the transposed arrays (nch rounded up to 64)
     int Lc;        // halo-tail length kept for the boundary check (<= H)
     int bits, epw, W;  // psi packing: bits per entry, entries per 32-bit word, words per sample
+    // time shard of a longer recording (hmmsort_plan_set_shard): statistics are accumulated for
+    // the owned samples/onsets [own_lo, own_hi) only; first/last: the shard starts/ends the recording
+    int64_t own_lo, own_hi;
+    int first, last;
 };
 
 // junction constants, passed to kernels by value (kernarg segment -> scalar loads)

@@ -27,6 +27,7 @@ bool ring_supported(const HostModel &m, int64_t T, std::string *why)
 static int make_geometry(RingGeom &g, int64_t T, int N, int L, int64_t block_req, int64_t halo_req)
 {
     g.T = T; g.N = N; g.L = L;
+    g.own_lo = 0; g.own_hi = T; g.first = 1; g.last = 1;
     // warm-up: four ring lengths, at least 256 samples (scripts/sweep_halo.py: at 10 M samples the
     // certificates pass at 256 on sparse and dense signals, 128 is flagged 4..64 times).  Whether
     // a warm-up was long enough is CERTIFIED on device after every call (k_halo_check,

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64) void k_post(RingGeom g, JParams<N> jp,
         double rv[N];
 #pragma unroll
         for (int a = 0; a < N; a++) rv[a] = 0.0;
-        if (s < nc) {
+        if (s < nc && tc + s >= g.own_lo && tc + s < g.own_hi) {  // owned samples / onsets only
             const int64_t t = tc + s;
             const int64_t offp = (int64_t)(H + s) * ncol + c, offq = (int64_t)(L + s) * ncol + c;
             const double a0 = A0[(int64_t)(1 + s) * ncol + c];
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64) void k_post(RingGeom g, JParams<N> jp,
             const double ga = ex[2 * N];
             const double yv = yT[off];
             s_all += ga;                                      // baumwelch.jl:303 qq
-            if (t < g.T - 1) s_m += ga;                       // :257 bb, t = 1..T-1
+            if (!g.last || t < g.T - 1) s_m += ga;            // :257 bb, t = 1..T-1 of the recording
             s_y2 += ga * (yv * yv);                           // :302 with the new silent mean (= 0)
 #pragma unroll
             for (int a = 0; a < N; a++) {
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_stats_edges(RingGeom g, const double *_
     for (int pair = threadIdx.x; pair < NL; pair += blockDim.x) {
         const int a = pair / L, k = pair % L + 1;
         double g0 = 0.0, g1 = 0.0, g2 = 0.0;
-        for (int j = 1; j <= L - 1; j++) {
+        for (int j = 1; j <= L - 1 && g.first; j++) {  // virtual onsets exist at the recording start only
             const int idx = -j + k - 1;
             if (idx < 0) continue;
             const double rv = fexp((P[a * planeP + (int64_t)(g.H - j) * ncol] +

@@ -61,6 +61,11 @@ class Plan:
         check(lib().hmmsort_plan_viterbi(self._h, _dptr(d_y), _dptr(d_x), _dptr(d_ll),
                                          C.c_void_p(stream)))
 
+    def set_shard(self, own_lo, own_hi, first, last):
+        """time shard of a longer recording: accumulate statistics for [own_lo, own_hi) only"""
+        check(lib().hmmsort_plan_set_shard(self._h, int(own_lo), int(own_hi), int(bool(first)),
+                                           int(bool(last))))
+
     def stats_len(self):
         return int(lib().hmmsort_plan_stats_len(self._h))
 

@@ -15,6 +15,18 @@ def shard_channels(n_channels, rank, world_size):
     return list(range(rank, n_channels, world_size))
 
 
+def time_shard(T, rank, world_size, halo):
+    """Slice of a T-sample recording for `rank`: returns (slice_lo, slice_hi, own_lo, own_hi, first,
+    last) with own_* in slice coordinates, for Plan.set_shard.  Owned ranges partition [0, T);
+    every slice carries `halo` extra samples on each interior side (warm-up / ring completion)."""
+    per = (T + world_size - 1) // world_size
+    lo, hi = min(T, rank * per), min(T, (rank + 1) * per)
+    first, last = rank == 0, hi >= T
+    s_lo = 0 if first else max(0, lo - halo)
+    s_hi = T if last else min(T, hi + halo)
+    return s_lo, s_hi, lo - s_lo, hi - s_lo, first, last
+
+
 def allreduce_stats(stats, group=None):
     """In-place SUM all-reduce of a statistics vector (torch tensor on the rank's device)."""
     import torch.distributed as dist

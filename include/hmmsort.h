@@ -175,6 +175,15 @@ int hmmsort_plan_estep(hmmsort_plan *plan, const double *d_y, double *d_stats, v
 int hmmsort_plan_decode_estep(hmmsort_plan *plan, const double *d_y, int16_t *d_x, double *d_ll,
                               double *d_stats, void *stream);
 int64_t hmmsort_plan_stats_len(const hmmsort_plan *plan);
+/* Time-sharding ONE recording over several plans/GPUs: the plan's signal is the slice
+ * [own_lo - halo_before, own_hi + halo_after) of the recording (halos of >= a few ring lengths;
+ * the slice's own ends act as warm-up), and the E-step accumulates statistics only for samples /
+ * ring onsets in [own_lo, own_hi) (slice coordinates).  `first` / `last` say whether the slice
+ * starts / ends the recording (the reference's first-column and terminal conditions apply there).
+ * Summing the statistics of all shards (SUM all-reduce) and calling hmmsort_plan_mstep gives the
+ * EM step of the whole recording.  pp (gamma[:,1]) is meaningful on the first shard only.
+ * Default: the plan owns everything (one shard = the recording). */
+int hmmsort_plan_set_shard(hmmsort_plan *plan, int64_t own_lo, int64_t own_hi, int first, int last);
 /* M-step finish from (all-reduced) statistics, on device: d_out receives
  * [mu (K*N) | sigma (1) | lp_new (N) | pp (S)] = K*N + 1 + N + S doubles. */
 int hmmsort_plan_mstep(hmmsort_plan *plan, const double *d_stats, double *d_out, void *stream);

@@ -155,3 +155,43 @@ def test_busy_signal_certificate_and_escalation(O, H):
     print("busy signal: escalations", esc, "diag", diag)
     assert (diag[3] + diag[5] > 0) == (esc > 0) or esc == 0
     assert max(diag[4], diag[6]) >= 0.0
+
+
+def test_time_sharded_estep_equals_whole_recording(O, H):
+    # one recording cut into 3 time shards (what 3 GPUs would hold): the shard statistics add up
+    # to the statistics of the whole recording, and the M-step from the sum matches the oracle
+    import torch
+    K, N, T = 40, 3, 90_000
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, 3.0, 0.8, 0.2),
+                                        H.create_spike_template(K, 4.0, 0.3, 0.2),
+                                        H.create_spike_template(K, 2.5, 0.6, 0.25)], 1))
+    pp = [0.004, 0.002, 0.003]
+    y = H.create_signal(T, 0.3, pp, temps, seed=17)
+    sm = H.StateMatrix.create(N, K, np.log(pp), False)
+    mu = np.asfortranarray(temps * 0.9)
+    mu[0, :] = 0
+    st = torch.cuda.current_stream().cuda_stream
+    whole = H.Plan(T, sm, mu, 0.35)
+    dy = torch.from_numpy(y).cuda()
+    ref = torch.zeros(whole.stats_len(), dtype=torch.float64, device="cuda")
+    whole.estep(dy, ref, st)
+    total = torch.zeros_like(ref)
+    world = 3
+    for rank in range(world):
+        s_lo, s_hi, o_lo, o_hi, first, last = H.dist.time_shard(T, rank, world, halo=1024)
+        plan = H.Plan(s_hi - s_lo, sm, mu, 0.35)
+        plan.set_shard(o_lo, o_hi, first, last)
+        part = torch.zeros_like(ref)
+        plan.estep(dy[s_lo:s_hi].contiguous(), part, st)
+        total += part
+        plan.close()
+    torch.cuda.synchronize()
+    r, t = ref.cpu().numpy(), total.cpu().numpy()
+    assert np.allclose(t, r, rtol=1e-9, atol=1e-12), np.abs(t - r).max()
+    out = torch.zeros(whole.mstep_len(), dtype=torch.float64, device="cuda")
+    whole.mstep(total, out, st)
+    o = out.cpu().numpy()
+    _, omu, osig, olp, _ = O.train_step(y, to_oracle_sm(O, sm), mu, 0.35)
+    assert np.allclose(o[:K * N].reshape((K, N), order="F"), omu, rtol=1e-8, atol=1e-11)
+    assert abs(o[K * N] - osig) <= 1e-8 * osig and np.allclose(o[K * N + 1:K * N + 1 + N], olp, rtol=1e-8)
+    whole.close()
