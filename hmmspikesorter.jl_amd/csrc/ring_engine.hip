@@ -180,6 +180,13 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T, int64_t block_req,
     if (hipMemset(r->diag, 0, 8 * sizeof(int64_t)) != hipSuccess) { ring_destroy(r); return HMMSORT_EHIP; }
     rc = ring_set_model(r, m);
     if (rc) { ring_destroy(r); return rc; }
+    if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming) != hipSuccess) {
+        set_error("ring engine: could not create the internal stream/events");
+        ring_destroy(r);
+        return HMMSORT_EHIP;
+    }
     *out = r;
     return HMMSORT_OK;
 }
@@ -192,6 +199,9 @@ void ring_destroy(RingDev *r)
                     r->part, r->Zc, r->Zp, r->B0h, r->partA, r->partS, r->rhoT, r->extra, r->pp, r->diag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
+    if (r->ev_join) (void)hipEventDestroy(r->ev_join);
+    if (r->side) (void)hipStreamDestroy(r->side);
     delete r;
 }
 

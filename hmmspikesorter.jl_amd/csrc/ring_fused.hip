@@ -53,8 +53,17 @@ int ring_decode_estep_launch(RingDev *r, const double *d_y, int16_t *d_x, double
         return HMMSORT_OK;
     });
     if (rc) return rc;
-    if ((rc = ring_viterbi_post(r, d_y, d_x, d_ll, st))) return rc;
-    return ring_estep_post(r, d_y, d_stats, st);
+    // After the sweeps the decode's post-processing (final state, backtrace, certificate, x, ll:
+    // a handful of small latency-bound kernels) and the E-step's (normaliser, posteriors,
+    // statistics) are independent: the former runs on the plan's internal stream beside the
+    // latter and is joined back into the caller's stream before returning.
+    HS_HIP(hipEventRecord(r->ev_fork, st));
+    HS_HIP(hipStreamWaitEvent(r->side, r->ev_fork, 0));
+    if ((rc = ring_viterbi_post(r, d_y, d_x, d_ll, r->side))) return rc;
+    HS_HIP(hipEventRecord(r->ev_join, r->side));
+    if ((rc = ring_estep_post(r, d_y, d_stats, st))) return rc;
+    HS_HIP(hipStreamWaitEvent(st, r->ev_join, 0));
+    return HMMSORT_OK;
 }
 
 }  // namespace hmmsort
