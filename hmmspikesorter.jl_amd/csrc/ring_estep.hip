@@ -603,6 +603,13 @@ int ring_estep_post(RingDev *r, const double *d_y, double *d_stats, hipStream_t 
                            r->Zp); }
         { PROF(r, "k_post", st); hipLaunchKernelGGL((k_post<NN>), dim3(colgroups, (g.B + kPostRows - 1) / kPostRows), dim3(64), 0, st, g, jp, r->yT, r->Rf, r->P,
                            r->Q, r->A0, r->B0, r->Zp, r->Zc, r->rhoT, r->partS); }
+        // the boundary certificate only needs the posteriors: it runs on the plan's internal
+        // stream beside the statistics kernels and is joined at the end of this function
+        HS_HIP(hipEventRecord(r->ev_post, st));
+        HS_HIP(hipStreamWaitEvent(r->side, r->ev_post, 0));
+        { PROF(r, "k_fb_check", r->side); hipLaunchKernelGGL((k_fb_check<NN>), dim3(colgroups), dim3(64 * kChkParts), 0, r->side, g, 1e-9, r->P, r->Q,
+                           r->A0, r->B0, r->B0h, r->Zc, r->rhoT, r->diag); }
+        HS_HIP(hipEventRecord(r->ev_chk, r->side));
         {
             const int nkb = (L + KB - 1) / KB;
             const size_t lds = ((size_t)NN * 16 * 64 + (size_t)(16 + nkb * KB - 1) * 64) * sizeof(double);
@@ -618,8 +625,7 @@ int ring_estep_post(RingDev *r, const double *d_y, double *d_stats, hipStream_t 
                            r->rhoT, r->partA); }
             }
         }
-        { PROF(r, "k_fb_check", st); hipLaunchKernelGGL((k_fb_check<NN>), dim3(colgroups), dim3(64 * kChkParts), 0, st, g, 1e-9, r->P, r->Q,
-                           r->A0, r->B0, r->B0h, r->Zc, r->rhoT, r->diag); }
+
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
     });
@@ -630,6 +636,7 @@ int ring_estep_post(RingDev *r, const double *d_y, double *d_stats, hipStream_t 
     { PROF(r, "k_stats_final", st); hipLaunchKernelGGL(k_stats_final, dim3(total), dim3(64), 0, st, N, L, colgroups,
                        colgroups * ((g.B + kPostRows - 1) / kPostRows), r->partA, r->partS, r->extra, d_stats); }
     HS_HIP(hipGetLastError());
+    HS_HIP(hipStreamWaitEvent(st, r->ev_chk, 0));
     return HMMSORT_OK;
 }
 
