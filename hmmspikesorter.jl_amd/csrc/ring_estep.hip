@@ -149,10 +149,13 @@ __global__ __launch_bounds__(64) void k_post(RingGeom g, JParams<N> jp,
             s_all += ga;                                      // baumwelch.jl:303 qq
             if (!g.last || t < g.T - 1) s_m += ga;            // :257 bb, t = 1..T-1 of the recording
             s_y2 += ga * (yv * yv);                           // :302 with the new silent mean (= 0)
+            // onsets whose ring runs past the end of the recording (t > T-L) are summed per phase
+            // in k_stats_edges: G0(a,k) must be a sum of positive terms, never "total - tail"
+            const bool bulk = !(g.last && t > g.T - L);
 #pragma unroll
             for (int a = 0; a < N; a++) {
                 rv[a] = ex[a];
-                ra[a] += ex[a];
+                ra[a] += bulk ? ex[a] : 0.0;
                 sx[a] += ex[N + a];
             }
         }
@@ -467,8 +470,8 @@ __global__ __launch_bounds__(512) void k_gsum_lds(RingGeom g, int nkb, const dou
 
 // virtual onsets t' = -j (rings already running at the first sample), the end-of-data correction
 // of G0 and pp = gamma[:,1] (baumwelch.jl:263).  One block.
-//   extra[0..NL)    = G0 contribution of virtual onsets  -  sum of rho over real onsets whose
-//                     phase k falls beyond the last sample (t' > T-k)
+//   extra[0..NL)    = G0 contribution of virtual onsets  +  sum of rho over the onsets of the last
+//                     L-1 samples that still reach phase k (k_post leaves those out of its total)
 //   extra[NL..2NL)  = G1 of virtual onsets,  extra[2NL..3NL) = G2 of virtual onsets
 __global__ __launch_bounds__(256) void k_stats_edges(RingGeom g, const double *__restrict__ y,
                                                      const double *__restrict__ P,
@@ -495,10 +498,12 @@ __global__ __launch_bounds__(256) void k_stats_edges(RingGeom g, const double *_
             const double yv = y[idx];
             g0 += rv; g1 += rv * yv; g2 += rv * (yv * yv);
         }
+        // truncated rings at the end of the recording: onsets t' in (T-L, T-k] still cover phase k
         double tail = 0.0;
-        for (int64_t t = g.T - k + 1; t < g.T; t++)
-            if (t >= 0) tail += rhoT[a * planeR + (t % g.B) * ncol + (t / g.B)];
-        extra[pair] = g0 - tail;
+        if (g.last)
+            for (int64_t t = g.T - L + 1; t <= g.T - k; t++)
+                if (t >= 0) tail += rhoT[a * planeR + (t % g.B) * ncol + (t / g.B)];
+        extra[pair] = g0 + tail;
         extra[NL + pair] = g1;
         extra[2 * NL + pair] = g2;
         const int sp = 1 - k;  // pp for state (a,k): the onset at t' = 1-k

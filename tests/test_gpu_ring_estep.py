@@ -40,6 +40,8 @@ def _compare_step(O, H, y, sm, mu, sigma, rtol=1e-8):
     (4, 60, 40_001, 4, 512, 256),
     (1, 40, 9_000, 5, 0, 0),
     (8, 33, 12_000, 6, 0, 0),
+    (16, 40, 10_000, 7, 0, 0),         # 16 rings (BASELINE config 5 ring count)
+    (8, 128, 9_000, 8, 0, 0),          # BASELINE config 4 model shape (S = 1017)
 ])
 def test_em_step_matches_oracle(O, H, N, K, T, seed, block, halo):
     rng = np.random.default_rng(seed)
@@ -49,7 +51,7 @@ def test_em_step_matches_oracle(O, H, N, K, T, seed, block, halo):
     amps = [(base[i % 4][0] * (1 + 0.13 * (i // 4)), base[i % 4][1] + 0.03 * (i // 4), base[i % 4][2])
             for i in range(N)]
     temps = np.asfortranarray(np.stack([H.create_spike_template(K, *a) for a in amps], 1))
-    pp = rng.uniform(1e-3, 4e-3, N)
+    pp = rng.uniform(1e-3, 4e-3, N) * min(1.0, 60.0 / K) * min(1.0, 4.0 / N)
     y = H.create_signal(T, 0.3, pp, temps, seed=seed)
     sm = H.StateMatrix.create(N, K, np.log(pp), False)
     mu = np.asfortranarray(temps * rng.uniform(0.7, 1.2, N)[None, :])

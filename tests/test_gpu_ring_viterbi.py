@@ -64,6 +64,8 @@ def test_golden_fixture(H, name):
     (4, 60, 100_000, 7, 1024, 512),
     (8, 128, 120_000, 8, 0, 0),        # BASELINE config 4 model shape (S = 1017)
     (16, 33, 60_000, 9, 0, 0),         # 16 rings: three psi words per sample
+    (16, 256, 40_000, 10, 0, 0),       # BASELINE config 5 model shape (S = 4081)
+    (16, 257, 30_000, 11, 0, 0),       # the "4097-state" reading of config 5
 ])
 def test_viterbi_bit_exact(O, H, N, K, T, seed, block, halo):
     rng = np.random.default_rng(seed)
@@ -73,7 +75,8 @@ def test_viterbi_bit_exact(O, H, N, K, T, seed, block, halo):
     amps = [(base[i % 4][0] * (1 + 0.13 * (i // 4)), base[i % 4][1] + 0.03 * (i // 4), base[i % 4][2])
             for i in range(N)]
     temps = np.asfortranarray(np.stack([H.create_spike_template(K, *a) for a in amps], 1))
-    pp = rng.uniform(5e-4, 3e-3, N)
+    # keep the fraction of time spent inside spikes comparable across model shapes
+    pp = rng.uniform(5e-4, 3e-3, N) * min(1.0, 60.0 / K) * min(1.0, 4.0 / N)
     y = H.create_signal(T, 0.3, pp, temps, seed=seed)
     sm = H.StateMatrix.create(N, K, np.log(pp), False)
     x, ll, diag, info = _decode_with_plan(H, y, sm, temps, 0.3)
