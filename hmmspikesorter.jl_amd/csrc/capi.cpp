@@ -3,7 +3,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <mutex>
 
 #include "hmmsort_internal.h"
 #include "ring_common.h"

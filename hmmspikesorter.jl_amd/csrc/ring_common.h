@@ -33,7 +33,7 @@ struct RingGeom {
     int B, H;      // chain length, warm-up length (multiples of 64, H <= B)
     int nch;       // chains = ceil(T/B); every chain has >= L samples
     int ncol;      // columns of the transposed arrays (nch rounded up to 64)
-    int Lc;        // halo-tail length kept for the boundary check (<= H)
+    int Lc;        // (unused)
     int bits, epw, W;  // psi packing: bits per entry, entries per 32-bit word, words per sample
     // time shard of a longer recording (hmmsort_plan_set_shard): statistics are accumulated for
     // the owned samples/onsets [own_lo, own_hi) only; first/last: the shard starts/ends the recording
@@ -96,7 +96,6 @@ struct RingDev {
     double *A0 = nullptr;         // (1+B) x ncol fwd silent (row 0 = value before the chain)
     double *B0 = nullptr;         // B x ncol bwd silent
     uint32_t *psi = nullptr;      // W planes of B x ncol
-    uint32_t *psiH = nullptr;     // W planes of Lc x ncol
     double *D0end = nullptr;      // ncol
     double *D0pre = nullptr;      // ncol: delta(silent) at tc-1 in chain c's warm-up frame
     int32_t *bstate = nullptr;    // ncol

@@ -50,7 +50,7 @@ static int make_geometry(RingGeom &g, int64_t T, int N, int L, int64_t block_req
     g.B = (int)B; g.H = (int)H;
     g.nch = (int)((T + B - 1) / B);
     g.ncol = (int)round_up(g.nch, 64);
-    g.Lc = (int)std::min<int64_t>(H, 2 * (int64_t)L);
+    g.Lc = 0;
     int bits = 1;
     while ((1 << bits) < N + 1) bits++;
     g.bits = bits; g.epw = 32 / bits; g.W = (N + 1 + g.epw - 1) / g.epw;
@@ -142,7 +142,6 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T, int64_t block_req,
     A(&r->A0, (int64_t)(1 + g.B) * g.ncol);
     A(&r->B0, BC);
     A(&r->psi, (int64_t)g.W * BC);
-    A(&r->psiH, (int64_t)g.W * g.Lc * g.ncol);
     A(&r->D0end, g.ncol);
     A(&r->D0pre, g.ncol);
     A(&r->bstate, g.ncol);
@@ -197,7 +196,7 @@ void ring_destroy(RingDev *r)
 {
     if (!r) return;
     void *ptrs[] = {r->d_mean, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->yT, r->Rf, r->P, r->Pv, r->Q, r->A0,
-                    r->B0, r->psi, r->psiH, r->D0end, r->D0pre, r->bstate, r->redo, r->xT, r->final_state,
+                    r->B0, r->psi, r->D0end, r->D0pre, r->bstate, r->redo, r->xT, r->final_state,
                     r->part, r->Zc, r->Zp, r->B0h, r->partA, r->partS, r->rhoT, r->extra, r->pp, r->diag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
