@@ -229,6 +229,34 @@ def main():
     t_vit = timed(lambda: plan.viterbi(dy, dx, dll, stream))       # each incl. its own pre-pass
     t_est = timed(lambda: (plan.estep(dy, stats, stream), plan.mstep(stats, out, stream)))
 
+    # ---- BASELINE config 3: full Baum-Welch EM, 10 iterations, device-resident (untimed extra) ----
+    # every iteration = E-step + M-step on the GPU, then the host part the reference also has:
+    # read back mu/sigma/lp (K*N+1+N doubles), rebuild the transition list, upload the new model
+    def em_iterations(n_iter=10):
+        rng = np.random.default_rng(7)
+        sig0 = float(np.std(y, ddof=1))
+        mu0 = np.ones((K, N), order="F")
+        for i in range(N):  # the reference's random start, baumwelch.jl:311-322
+            mu0[:, i] = H.create_spike_template(K, 3 * sig0 * rng.random(), 0.5 + 0.1 * rng.standard_normal(),
+                                                1.5 * rng.random())
+        mu0[0, :] = 0.0
+        sm_i = H.StateMatrix.create(N, K, np.log(np.full(N, 2.0 ** (-3 * K / 2))), False)
+        em = H.Plan(T, sm_i, mu0, sig0)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n_iter):
+            em.estep(dy, stats, stream)
+            em.mstep(stats, out, stream)
+            o = out.cpu().numpy()
+            mu_i = np.asfortranarray(o[:K * N].reshape((K, N), order="F"))
+            sm_i = H.StateMatrix.from_states(sm_i.states, o[K * N + 1 + N:], K, o[K * N + 1:K * N + 1 + N], False)
+            em.set_model(sm_i, mu_i, float(o[K * N]))
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t) / n_iter
+        em.close()
+        return per * 1e3, float(o[K * N])
+    em_ms, em_sigma = em_iterations() if not args.time_sharded else (None, None)
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         res = {
@@ -261,6 +289,7 @@ def main():
             "detail": {"viterbi_Msamples_s": T / t_vit / 1e6, "estep_Msamples_s": T / t_est / 1e6,
                        "kernel_ms": {k: round(v, 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1])},
                        "sum_kernel_ms_per_step": step_ms_kernels,
+                       "em_iteration_ms": em_ms, "em_sigma_after_10": em_sigma,
                        "diag": diag[:7], "workspace_GB": info["workspace_bytes"] / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline:
