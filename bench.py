@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--time-sharded", action="store_true",
                     help="strong scaling: ONE recording of --samples cut into time shards, one per "
                          "rank, statistics SUM-all-reduced every step (default: one channel per rank)")
+    ap.add_argument("--channels", type=int, default=4,
+                    help="extra (untimed) measurement: this many channels per GPU on concurrent streams")
     ap.add_argument("--separate", action="store_true",
                     help="decode and E-step as two calls instead of hmmsort_plan_decode_estep")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
@@ -257,6 +259,33 @@ def main():
         return per * 1e3, float(o[K * N])
     em_ms, em_sigma = em_iterations() if not args.time_sharded else (None, None)
 
+    # ---- several channels per GPU, one plan + one stream each (the serving shape of a multi-
+    # channel probe; untimed extra, reported in detail only) ----
+    def multi_channel(nchan):
+        plans, streams, bufs = [], [], []
+        for ch in range(nchan):
+            pl = H.Plan(T, sm, temps, sigma)
+            stc = torch.cuda.Stream()
+            yy = dy if ch == 0 else torch.from_numpy(H.create_signal(T, sigma, pp, temps, seed=seed + 100 + ch)).to(dev)
+            bufs.append((yy, torch.zeros(T, dtype=torch.int16, device=dev),
+                         torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros_like(stats),
+                         torch.zeros_like(out)))
+            plans.append(pl); streams.append(stc)
+        def go():
+            for pl, stc, (yy, xx, ll_, ss, oo) in zip(plans, streams, bufs):
+                h = stc.cuda_stream
+                pl.bind(yy, h); pl.decode_estep(yy, xx, ll_, ss, h); pl.mstep(ss, oo, h); pl.unbind()
+        go(); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            go()
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t) / 3
+        for pl in plans:
+            pl.close()
+        return nchan * T / per / 1e6
+    mc = multi_channel(args.channels) if (args.channels > 1 and not args.time_sharded) else None
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         res = {
@@ -290,6 +319,7 @@ def main():
                        "kernel_ms": {k: round(v, 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1])},
                        "sum_kernel_ms_per_step": step_ms_kernels,
                        "em_iteration_ms": em_ms, "em_sigma_after_10": em_sigma,
+                       "multi_channel": {"channels_per_gpu": args.channels, "Msamples_s": mc} if mc else None,
                        "diag": diag[:7], "workspace_GB": info["workspace_bytes"] / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline:
