@@ -369,8 +369,9 @@ __global__ __launch_bounds__(64 * kChkParts) void k_fb_check(RingGeom g, double 
     }
 }
 
-// LDS-tiled variant of k_gsum for nkb = ceil(L/KB) <= 8 (512 threads keep 256 VGPRs per lane):
-// one workgroup = 64 chain columns, wave w = phase group w (surplus waves only help staging).
+// LDS-tiled variant of k_gsum: one workgroup = 64 chain columns x 8 consecutive phase groups
+// (blockIdx.y selects which 8; 512 threads keep 256 VGPRs per lane), wave w = phase group
+// 8*blockIdx.y + w (surplus waves only help staging).
 // A tile of TR onset rows of rho (all rings) and the TR + nkb*KB - 1 rows of y they touch are
 // staged ONCE in LDS (coalesced global rows -> [row][lane], conflict-free reads) and consumed by
 // all phase groups, instead of every phase group streaming them from L2.  Staging goes through
@@ -387,11 +388,15 @@ __global__ __launch_bounds__(512) void k_gsum_lds(RingGeom g, int nkb, const dou
     const int lane = threadIdx.x & 63, kbi = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 64;
     const int B = g.B, L = g.L, ncol = g.ncol;
-    const int YR = TR + nkb * KB - 1;
+    const int kb0 = blockIdx.y * 8;           // first phase group of this workgroup
+    const int nloc = nkb - kb0 < 8 ? nkb - kb0 : 8;
+    const int YR = TR + nloc * KB - 1;
+    const int yoff = kb0 * KB;                // y rows of this workgroup start at s0 + yoff
     double *lrho = lds;                       // [N][TR][64]
     double *ly = lds + (size_t)N * TR * 64;   // [YR][64]
     const int64_t planeR = (int64_t)B * ncol;
-    const int k0 = kbi * KB + 1;
+    const int kl = kbi * KB + 1;              // first phase relative to the staged y window
+    const int k0 = yoff + kl;
     double g1[N][KB], g2[N][KB], w[KB];
 #pragma unroll
     for (int a = 0; a < N; a++)
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(512) void k_gsum_lds(RingGeom g, int nkb, const dou
 #pragma unroll
         for (int q = 0; q < NYM; q++) {
             const int i = threadIdx.x + q * 512;
-            const int ln = i & 63, r = s0 + (i >> 6);
+            const int ln = i & 63, r = s0 + yoff + (i >> 6);
             const int cc = c0 + ln;
             const bool ok = i < YR * 64 && cc < g.nch && (int64_t)cc * B + r < g.T;
             const int rr = ok ? r : 0, cq = ok ? cc : 0;
@@ -425,16 +430,16 @@ __global__ __launch_bounds__(512) void k_gsum_lds(RingGeom g, int nkb, const dou
             if (i < YR * 64) ly[i] = ty_[q];
         }
         __syncthreads();
-        if (kbi >= nkb) continue;  // surplus waves only help staging (wave-uniform)
+        if (kbi >= nloc) continue;  // surplus waves only help staging (wave-uniform)
         // window for onset row u: w[(u + j) % KB] = y[row s0 + u + k0 - 1 + j]
 #pragma unroll
-        for (int j = 0; j < KB - 1; j++) w[j] = ly[(k0 - 1 + j) * 64 + lane];
+        for (int j = 0; j < KB - 1; j++) w[j] = ly[(kl - 1 + j) * 64 + lane];
 #pragma unroll
         for (int ub = 0; ub < TR; ub += KB) {
 #pragma unroll
             for (int uu = 0; uu < KB; uu++) {
                 const int u = ub + uu;
-                w[(uu + KB - 1) % KB] = ly[(u + k0 + KB - 2) * 64 + lane];
+                w[(uu + KB - 1) % KB] = ly[(u + kl + KB - 2) * 64 + lane];
                 double rv[N];
 #pragma unroll
                 for (int a = 0; a < N; a++) rv[a] = lrho[(a * TR + u) * 64 + lane];
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(512) void k_gsum_lds(RingGeom g, int nkb, const dou
             }
         }
     }
-    if (kbi >= nkb) return;
+    if (kbi >= nloc) return;
     const int NL = N * L;
     double *out = partG + (size_t)blockIdx.x * 2 * NL;
 #pragma unroll
@@ -469,11 +474,11 @@ __global__ __launch_bounds__(512) void k_gsum_lds(RingGeom g, int nkb, const dou
 }
 
 // virtual onsets t' = -j (rings already running at the first sample), the end-of-data correction
-// of G0 and pp = gamma[:,1] (baumwelch.jl:263).  One block.
+// of G0 and pp = gamma[:,1] (baumwelch.jl:263).  One thread per ring state.
 //   extra[0..NL)    = G0 contribution of virtual onsets  +  sum of rho over the onsets of the last
 //                     L-1 samples that still reach phase k (k_post leaves those out of its total)
 //   extra[NL..2NL)  = G1 of virtual onsets,  extra[2NL..3NL) = G2 of virtual onsets
-__global__ __launch_bounds__(256) void k_stats_edges(RingGeom g, const double *__restrict__ y,
+__global__ __launch_bounds__(64) void k_stats_edges(RingGeom g, const double *__restrict__ y,
                                                      const double *__restrict__ P,
                                                      const double *__restrict__ Q,
                                                      const double *__restrict__ A0,
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(256) void k_stats_edges(RingGeom g, const double *_
     const int64_t planeP = (int64_t)(g.H + g.B) * ncol, planeQ = (int64_t)(L + g.B + g.H) * ncol,
                   planeR = (int64_t)g.B * ncol;
     const double z = Zc[0];
-    for (int pair = threadIdx.x; pair < NL; pair += blockDim.x) {
+    for (int pair = blockIdx.x * blockDim.x + threadIdx.x; pair < NL; pair += gridDim.x * blockDim.x) {
         const int a = pair / L, k = pair % L + 1;
         double g0 = 0.0, g1 = 0.0, g2 = 0.0;
         for (int j = 1; j <= L - 1 && g.first; j++) {  // virtual onsets exist at the recording start only
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(256) void k_stats_edges(RingGeom g, const double *_
         pp[1 + pair] = (P[a * planeP + (int64_t)(g.H + sp) * ncol] +
                         Q[a * planeQ + (int64_t)(L + sp) * ncol]) - z;
     }
-    if (threadIdx.x == 0) pp[0] = (A0[(int64_t)1 * ncol] + B0[0]) - z;
+    if (blockIdx.x == 0 && threadIdx.x == 0) pp[0] = (A0[(int64_t)1 * ncol] + B0[0]) - z;
 }
 
 // deterministic final assembly: stats = [G0 | G1 | G2 | Xi | s_all | s_m | s_y2 | 0];
@@ -617,13 +622,13 @@ int ring_estep_post(RingDev *r, const double *d_y, double *d_stats, hipStream_t 
         HS_HIP(hipEventRecord(r->ev_chk, r->side));
         {
             const int nkb = (L + KB - 1) / KB;
-            const size_t lds = ((size_t)NN * 16 * 64 + (size_t)(16 + nkb * KB - 1) * 64) * sizeof(double);
-            if (nkb <= 8 && NN * 16 * 64 % 512 == 0 && lds <= 150 * 1024 && g.B % 16 == 0) {
+            const size_t lds = ((size_t)NN * 16 * 64 + (size_t)(16 + 8 * KB - 1) * 64) * sizeof(double);
+            if (NN * 16 * 64 % 512 == 0 && lds <= 150 * 1024 && g.B % 16 == 0 && g.B >= L + 16 + 8 * KB) {
                 if (lds > 64 * 1024)
                     HS_HIP(hipFuncSetAttribute((const void *)k_gsum_lds<NN>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 PROF(r, "k_gsum", st);
-                hipLaunchKernelGGL((k_gsum_lds<NN>), dim3(colgroups), dim3(512), lds, st, g, nkb, r->yT,
+                hipLaunchKernelGGL((k_gsum_lds<NN>), dim3(colgroups, (nkb + 7) / 8), dim3(512), lds, st, g, nkb, r->yT,
                                    r->rhoT, r->partA);
             } else {
                 { PROF(r, "k_gsum", st); hipLaunchKernelGGL((k_gsum<NN>), dim3(((colgroups + 7) / 8) * 8 * ((L + KB - 1) / KB)), dim3(64), 0, st, g, r->yT,
@@ -635,7 +640,7 @@ int ring_estep_post(RingDev *r, const double *d_y, double *d_stats, hipStream_t 
         return HMMSORT_OK;
     });
     if (rc) return rc;
-    { PROF(r, "k_stats_edges", st); hipLaunchKernelGGL(k_stats_edges, dim3(1), dim3(256), 0, st, g, d_y, r->P, r->Q, r->A0, r->B0,
+    { PROF(r, "k_stats_edges", st); hipLaunchKernelGGL(k_stats_edges, dim3((NL + 63) / 64), dim3(64), 0, st, g, d_y, r->P, r->Q, r->A0, r->B0,
                        r->Zc, r->rhoT, r->extra, r->pp); }
     const int total = 3 * NL + N + 4;
     { PROF(r, "k_stats_final", st); hipLaunchKernelGGL(k_stats_final, dim3(total), dim3(64), 0, st, N, L, colgroups,
