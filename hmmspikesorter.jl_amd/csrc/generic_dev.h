@@ -15,6 +15,8 @@ struct GenericDev {
     double *d_pv = nullptr;   // T path values
     double *d_last = nullptr; // S last trellis column
     double *d_upd = nullptr;  // update() scratch
+    double *d_gbuf = nullptr; // 3*S state-vector scratch when LDS is too small
+    bool use_global = false;
     int64_t upd_bytes = 0;
     int threads = 256;
     int64_t bytes = 0;

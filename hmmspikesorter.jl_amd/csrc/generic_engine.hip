@@ -44,10 +44,13 @@ __global__ void gen_viterbi_sweep(const double *__restrict__ y, int64_t T, int S
                                   const int32_t *__restrict__ in_ptr,
                                   const int32_t *__restrict__ in_src,
                                   const double *__restrict__ in_lp, double c0, double den,
-                                  int16_t *__restrict__ T2, double *__restrict__ last)
+                                  int16_t *__restrict__ T2, double *__restrict__ last,
+                                  double *gbuf)
 {
+    // state vectors in LDS, or -- when 2*S doubles exceed it (large overlap models) -- in a global
+    // scratch that stays in this CU's L1/L2; one workgroup, so __syncthreads() orders the accesses
     extern __shared__ double sh[];
-    double *prev = sh, *cur = sh + S;
+    double *prev = gbuf ? gbuf : sh, *cur = prev + S;
     const int tid = threadIdx.x, nt = blockDim.x;
     // viterbi.jl:55-63  first column: emission only, then T1[1,1] = 0
     {
@@ -153,10 +156,10 @@ __global__ void gen_forward_sweep(const double *__restrict__ y, int64_t T, int S
                                   const int32_t *__restrict__ in_ptr,
                                   const int32_t *__restrict__ in_src,
                                   const double *__restrict__ in_lp, double c0, double den,
-                                  double *__restrict__ alpha)
+                                  double *__restrict__ alpha, double *gbuf)
 {
     extern __shared__ double sh[];
-    double *prev = sh, *cur = sh + S;
+    double *prev = gbuf ? gbuf : sh, *cur = prev + S;
     const int tid = threadIdx.x, nt = blockDim.x;
     {
         const double y0 = y[0];
@@ -188,10 +191,10 @@ __global__ void gen_backward_sweep(const double *__restrict__ y, int64_t T, int 
                                    const int32_t *__restrict__ out_ptr,
                                    const int32_t *__restrict__ out_dst,
                                    const double *__restrict__ out_lp, double c0, double den,
-                                   double *__restrict__ beta)
+                                   double *__restrict__ beta, double *gbuf)
 {
     extern __shared__ double sh[];
-    double *nxt = sh, *cur = sh + S, *bq = sh + 2 * S;
+    double *nxt = gbuf ? gbuf : sh, *cur = nxt + S, *bq = nxt + 2 * S;
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int j = tid; j < S; j += nt) {  // baumwelch.jl:80
         cur[j] = 0.0;
@@ -365,16 +368,19 @@ int generic_set_model(GenericDev *g, const HostModel &m)
 int generic_create(GenericDev **out, const HostModel &m, int64_t T)
 {
     HS_CHECK(T >= 1, HMMSORT_EINVAL, "generic engine: T must be >= 1");
-    // LDS budget: 3*S doubles (backward) must fit 160 KiB
-    HS_CHECK(3 * m.S * 8 <= 160 * 1024, HMMSORT_EUNSUP,
-             "generic engine: %lld states do not fit LDS (max %d)", (long long)m.S,
-             160 * 1024 / 24);
     GenericDev *g = new GenericDev();
     g->N = m.N; g->K = m.K; g->S = m.S; g->R = m.R; g->T = T;
     int th = (int)((m.S + 63) / 64 * 64);
     g->threads = th < 64 ? 64 : (th > 1024 ? 1024 : th);
     int rc = generic_set_model(g, m);
     if (rc) { generic_destroy(g); return rc; }
+    // LDS budget: 3*S doubles (backward sweep) within 150 KiB, else a global scratch
+    g->use_global = 3 * m.S * 8 > 150 * 1024;
+    if (g->use_global && hipMalloc((void **)&g->d_gbuf, 3 * m.S * sizeof(double)) != hipSuccess) {
+        set_error("generic engine: hipMalloc failed");
+        generic_destroy(g);
+        return HMMSORT_ENOMEM;
+    }
     if (hipMalloc((void **)&g->d_last, m.S * sizeof(double)) != hipSuccess) {
         set_error("generic engine: hipMalloc failed");
         generic_destroy(g);
@@ -390,7 +396,7 @@ void generic_destroy(GenericDev *g)
     if (!g) return;
     void *ptrs[] = {g->d_mean, g->d_in_lp, g->d_out_lp, g->d_mu, g->d_in_ptr, g->d_in_src,
                     g->d_out_ptr, g->d_out_dst, g->d_states, g->d_T2, g->d_pv, g->d_last,
-                    g->d_upd};
+                    g->d_upd, g->d_gbuf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -422,12 +428,12 @@ int generic_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     }
     const double c0 = -kLog2Pi - g->lsig;
     const double den = 2.0 * (g->sigma * g->sigma);
-    size_t lds = 2 * S * sizeof(double);
+    size_t lds = g->use_global ? 0 : 2 * S * sizeof(double);
     int rc = set_lds_limit((const void *)gen_viterbi_sweep, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(gen_viterbi_sweep, dim3(1), dim3(g->threads), lds, st, d_y, T, (int)S,
                        g->d_mean, g->d_in_ptr, g->d_in_src, g->d_in_lp, c0, den, g->d_T2,
-                       g->d_last);
+                       g->d_last, g->use_global ? g->d_gbuf : nullptr);
     HS_HIP(hipGetLastError());
     int W = (int)std::max<int64_t>(1, (48 * 1024) / (S * 2));
     size_t lds2 = (size_t)W * S * sizeof(int16_t);
@@ -447,11 +453,12 @@ int generic_forward(GenericDev *g, const double *d_y, double *d_alpha, hipStream
     // funcl 3-arg form (utils.jl:3): -log2pi - log(sigma) - ...; same constant as the 4-arg form
     const double c0 = -kLog2Pi - g->lsig;
     const double den = 2.0 * (g->sigma * g->sigma);
-    size_t lds = 2 * g->S * sizeof(double);
+    size_t lds = g->use_global ? 0 : 2 * g->S * sizeof(double);
     int rc = set_lds_limit((const void *)gen_forward_sweep, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(gen_forward_sweep, dim3(1), dim3(g->threads), lds, st, d_y, g->T, (int)g->S,
-                       g->d_mean, g->d_in_ptr, g->d_in_src, g->d_in_lp, c0, den, d_alpha);
+                       g->d_mean, g->d_in_ptr, g->d_in_src, g->d_in_lp, c0, den, d_alpha,
+                       g->use_global ? g->d_gbuf : nullptr);
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }
@@ -460,12 +467,12 @@ int generic_backward(GenericDev *g, const double *d_y, double *d_beta, hipStream
 {
     const double c0 = -kLog2Pi - g->lsig;
     const double den = 2.0 * (g->sigma * g->sigma);
-    size_t lds = 3 * g->S * sizeof(double);
+    size_t lds = g->use_global ? 0 : 3 * g->S * sizeof(double);
     int rc = set_lds_limit((const void *)gen_backward_sweep, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(gen_backward_sweep, dim3(1), dim3(g->threads), lds, st, d_y, g->T,
                        (int)g->S, g->d_mean, g->d_out_ptr, g->d_out_dst, g->d_out_lp, c0, den,
-                       d_beta);
+                       d_beta, g->use_global ? g->d_gbuf : nullptr);
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }

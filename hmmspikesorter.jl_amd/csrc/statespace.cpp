@@ -112,14 +112,12 @@ extern "C" int64_t hmmsort_build_transitions(int64_t N, int64_t K, const double 
     auto emit_row = [&](int64_t src) {
         // forced moves of the active neurons
         int nact_next = 0;
-        bool dead = false;
         std::vector<int> silent;
         for (int i = 0; i < N; i++) {
             if (ph[i] == 0) { silent.push_back(i); nx[i] = 0; }
             else if (ph[i] < L) { nx[i] = ph[i] + 1; nact_next++; }
             else { nx[i] = 0; }  // phase K-1 -> 0
         }
-        (void)dead;
         cands.clear();
         const int ns = (int)silent.size();
         const int room = maxact - nact_next;  // how many silent neurons may start

@@ -179,3 +179,23 @@ def test_extract_spiketimes(O, H):
         ref = O.extract_spiketimes(model.ml_seq, to_oracle_sm(O, sm), temps)
         assert len(got) == 2 and all(np.array_equal(g, r) for g, r in zip(got, ref))
         assert all(len(g) > 10 and np.all(np.diff(g) > 0) for g in got)
+
+
+def test_large_overlap_model_uses_global_state_vectors(O, H):
+    # N=4, K=40 with overlaps: 9283 states (the CLI's allow_overlaps=true, src/hmmsort.jl:54, with
+    # 4 templates); the state vectors no longer fit LDS and live in a global scratch
+    K, N, T = 40, 4, 1500
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, a, b, c) for a, b, c in
+                                        [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)]], 1))
+    pp = [0.006, 0.004, 0.005, 0.004]
+    sm = H.StateMatrix.create(N, K, np.log(pp), True)
+    assert sm.nstates == 1 + 4 * 39 + 6 * 39 * 39
+    y = H.create_signal(T, 0.3, pp, temps, seed=8)
+    y[300:300 + K] += temps[:, 1]                      # an overlapping pair of spikes
+    x, ll = H.viterbi(y, sm, temps, 0.3)
+    xo, llo = O.viterbi(y, to_oracle_sm(O, sm), temps, 0.3)
+    assert np.array_equal(x, xo) and ll == llo
+    assert x.max() > 1 + 4 * 39                        # a pair state was decoded
+    a = H.forward(y[:200], sm, temps, 0.3)
+    ao = O.forward(y[:200], to_oracle_sm(O, sm), temps, 0.3)
+    assert np.allclose(a, ao, rtol=1e-10, atol=0)
