@@ -73,10 +73,17 @@ int plan_create_engine(hmmsort_plan **out, int64_t T, const int16_t *states, int
         set_error("ring engine unavailable for this model/signal: %s", why.c_str());
         return HMMSORT_EUNSUP;
     }
-    if (engine_req != HMMSORT_ENGINE_STRICT && ring_ok) {
+    const bool want_ring = engine_req == HMMSORT_ENGINE_AUTO || engine_req == HMMSORT_ENGINE_RING;
+    if (want_ring && ring_ok) {
         p->engine = HMMSORT_ENGINE_RING;
         rc = ring_create(&p->ring, p->model, T, options().block,
                          halo_req >= 0 ? halo_req : options().halo);
+    } else if (engine_req == HMMSORT_ENGINE_BLOCKED ||
+               (engine_req == HMMSORT_ENGINE_AUTO && T >= blocked_min_samples())) {
+        // overlap models and other lists the ring engine does not take: blocked sweep
+        p->engine = HMMSORT_ENGINE_BLOCKED;
+        rc = generic_create(&p->gen, p->model, T, true, options().block,
+                            halo_req >= 0 ? halo_req : options().halo);
     } else {
         p->engine = HMMSORT_ENGINE_STRICT;
         rc = generic_create(&p->gen, p->model, T);
@@ -117,7 +124,7 @@ int hmmsort_set_option(const char *key, int64_t value)
     HS_CHECK(key, HMMSORT_EINVAL, "set_option: null key");
     Options &o = options();
     if (!strcmp(key, "engine")) {
-        HS_CHECK(value >= 0 && value <= 2, HMMSORT_EINVAL, "set_option: engine must be 0, 1 or 2");
+        HS_CHECK(value >= 0 && value <= 3, HMMSORT_EINVAL, "set_option: engine must be 0..3");
         o.engine = value;
     } else if (!strcmp(key, "block")) {
         HS_CHECK(value >= 0, HMMSORT_EINVAL, "set_option: block must be >= 0");
@@ -171,7 +178,7 @@ int hmmsort_plan_set_model(hmmsort_plan *p, const hmm_trans *tr, int64_t R, cons
     std::vector<int16_t> st = p->model.states;
     int rc = build_host_model(m, st.data(), p->model.N, p->model.K, p->model.S, tr, R, mu, sigma);
     if (rc) return rc;
-    if (p->engine == HMMSORT_ENGINE_RING) {
+    if (p->ring) {
         HS_CHECK(m.ring.valid, HMMSORT_EUNSUP, "plan_set_model: new model is not a ring model");
         rc = ring_set_model(p->ring, m);
     } else {
@@ -200,7 +207,7 @@ int hmmsort_plan_info(const hmmsort_plan *p, int64_t *engine, int64_t *block, in
         ring_geometry(p->ring, &b, &h, &n);
         w = ring_workspace_bytes(p->ring);
     } else if (p->gen) {
-        b = p->T; n = 1;
+        generic_geometry(p->gen, &b, &h, &n);
         w = generic_workspace_bytes(p->gen);
     }
     if (engine) *engine = p->engine;
@@ -282,6 +289,7 @@ int hmmsort_plan_diagnostics(hmmsort_plan *p, void *stream, int64_t diag[8])
     HS_CHECK(p && diag, HMMSORT_EINVAL, "plan_diagnostics: null argument");
     for (int i = 0; i < 8; i++) diag[i] = 0;
     if (p->ring) return ring_diagnostics(p->ring, (hipStream_t)stream, diag);
+    if (p->gen) return generic_diagnostics(p->gen, (hipStream_t)stream, diag);
     return HMMSORT_OK;
 }
 
@@ -326,7 +334,8 @@ int hmmsort_plan_profile_read(hmmsort_plan *p, void *stream, char *names, int64_
 static int64_t next_halo(const hmmsort_plan *p)
 {
     int64_t b = 0, h = 0, n = 0;
-    ring_geometry(p->ring, &b, &h, &n);
+    if (p->ring) ring_geometry(p->ring, &b, &h, &n);
+    else generic_geometry(p->gen, &b, &h, &n);
     return h * 2;
 }
 
@@ -352,15 +361,15 @@ int hmmsort_viterbi(const double *y, int64_t T, const int16_t *states, int64_t N
         rc = hmmsort_plan_viterbi(pg.p, dy.as<double>(), dx.as<int16_t>(), dll.as<double>(), nullptr);
         if (rc) return rc;
         HS_HIP(hipDeviceSynchronize());
-        if (!pg.p->ring) break;
+        if (pg.p->engine == HMMSORT_ENGINE_STRICT) break;
         int64_t diag[8];
-        if ((rc = ring_diagnostics(pg.p->ring, nullptr, diag))) return rc;
+        if ((rc = hmmsort_plan_diagnostics(pg.p, nullptr, diag))) return rc;
         if (diag[0] == 0 || !options().escalate) break;
         options().last_escalations = attempt + 1;
         halo = next_halo(pg.p);
         if (attempt >= 3 || halo > T) {
-            HS_CHECK(options().engine != HMMSORT_ENGINE_RING, HMMSORT_ENOCONV,
-                     "viterbi: %lld chain boundaries still fail the warm-up check", (long long)diag[0]);
+            HS_CHECK(options().engine == HMMSORT_ENGINE_AUTO, HMMSORT_ENOCONV,
+                     "viterbi: %lld block boundaries still fail the warm-up check", (long long)diag[0]);
             engine = HMMSORT_ENGINE_STRICT;
         }
     }
@@ -470,7 +479,11 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
         if (pg.p) { hmmsort_plan_destroy(pg.p); pg.p = nullptr; }
         rc = plan_create_engine(&pg.p, T, states, N, K, S, tr, R, mu_inout, sigma, engine, halo);
         if (rc) return rc;
-        if (!pg.p->ring) break;
+        if (!pg.p->ring) {
+            if (pg.p->engine == HMMSORT_ENGINE_STRICT) break;
+            engine = HMMSORT_ENGINE_STRICT;  // materialised alpha/beta are the strict engine's job
+            continue;
+        }
         const int64_t nlp = N;
         DevBuf dstats, dout;
         if ((rc = dstats.alloc(ring_stats_len(pg.p->ring) * sizeof(double))) ||

@@ -17,9 +17,27 @@ struct GenericDev {
     double *d_upd = nullptr;  // update() scratch
     double *d_gbuf = nullptr; // 3*S state-vector scratch when LDS is too small
     bool use_global = false;
+    // blocked (time-parallel) Viterbi, generic_blocked.hip
+    bool blocked = false, blk_cols_lds = true, blk_tail_lds = true;
+    int64_t B = 0, H = 0, nblk = 0;
+    int ntail = -1;
+    double *d_lp0 = nullptr, *d_tlp = nullptr, *d_endv = nullptr, *d_warmv = nullptr;
+    double *d_llpart = nullptr, *d_blkbuf = nullptr;
+    int32_t *d_src0 = nullptr, *d_tinfo = nullptr, *d_tsrc = nullptr;
+    int16_t *d_fmap = nullptr, *d_endstate = nullptr;
+    int64_t *d_merged = nullptr;
+    unsigned long long *d_bdiag = nullptr;
     int64_t upd_bytes = 0;
     int threads = 256;
     int64_t bytes = 0;
 };
+
+int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t halo_req);
+int blocked_set_model(GenericDev *g, const HostModel &m);
+void blocked_destroy(GenericDev *g);
+int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st);
+int blocked_diagnostics(GenericDev *g, hipStream_t st, int64_t diag[8]);
+void blocked_geometry(int64_t T, int64_t L, int64_t block_req, int64_t halo_req, int64_t *B,
+                      int64_t *H, int64_t *nblk);
 
 }  // namespace hmmsort

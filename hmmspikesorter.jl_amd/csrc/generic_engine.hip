@@ -362,10 +362,12 @@ int generic_set_model(GenericDev *g, const HostModel &m)
     if ((rc = upload(&g->d_mu, m.mu, &g->bytes))) return rc;
     if ((rc = upload(&g->d_states, m.states, &g->bytes))) return rc;
     g->nsrc1 = m.out_ptr[1] - m.out_ptr[0];
+    if (g->blocked) return blocked_set_model(g, m);
     return HMMSORT_OK;
 }
 
-int generic_create(GenericDev **out, const HostModel &m, int64_t T)
+int generic_create(GenericDev **out, const HostModel &m, int64_t T, bool blocked,
+                   int64_t block_req, int64_t halo_req)
 {
     HS_CHECK(T >= 1, HMMSORT_EINVAL, "generic engine: T must be >= 1");
     GenericDev *g = new GenericDev();
@@ -387,6 +389,10 @@ int generic_create(GenericDev **out, const HostModel &m, int64_t T)
         return HMMSORT_ENOMEM;
     }
     g->bytes += m.S * sizeof(double);
+    if (blocked && (rc = blocked_create(g, m, block_req, halo_req))) {
+        generic_destroy(g);
+        return rc;
+    }
     *out = g;
     return HMMSORT_OK;
 }
@@ -399,11 +405,27 @@ void generic_destroy(GenericDev *g)
                     g->d_upd, g->d_gbuf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    blocked_destroy(g);
     delete g;
 }
 
 int64_t generic_workspace_bytes(const GenericDev *g) { return g->bytes; }
 int64_t generic_n_lp(const GenericDev *g) { return g->nsrc1 - 1; }
+bool generic_is_blocked(const GenericDev *g) { return g->blocked; }
+int64_t blocked_min_samples() { return 4096; }
+
+void generic_geometry(const GenericDev *g, int64_t *block, int64_t *halo, int64_t *nblocks)
+{
+    *block = g->blocked ? g->B : g->T;
+    *halo = g->blocked ? g->H : 0;
+    *nblocks = g->blocked ? g->nblk : 1;
+}
+
+int generic_diagnostics(GenericDev *g, hipStream_t st, int64_t diag[8])
+{
+    if (g->blocked) return blocked_diagnostics(g, st, diag);
+    return HMMSORT_OK;
+}
 
 static int set_lds_limit(const void *fn, size_t bytes)
 {
@@ -415,6 +437,7 @@ static int set_lds_limit(const void *fn, size_t bytes)
 int generic_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st)
 {
     const int64_t T = g->T, S = g->S;
+    if (g->blocked) return blocked_viterbi(g, d_y, d_x, d_ll, st);
     if (!g->d_T2) {
         const double need = (double)S * (double)T * 2.0 + (double)T * 8.0;
         HS_CHECK(need < 200e9, HMMSORT_ENOMEM,

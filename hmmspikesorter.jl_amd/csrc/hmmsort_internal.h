@@ -80,7 +80,13 @@ struct GenericDev;  // generic_engine.hip
 struct RingDev;     // ring_engine.hip
 
 // generic (strict) engine: single sequential sweep in the reference's operation order
-int generic_create(GenericDev **g, const HostModel &m, int64_t T);
+// blocked = time-parallel Viterbi over blocks with a certified warm-up (generic_blocked.hip)
+int generic_create(GenericDev **g, const HostModel &m, int64_t T, bool blocked = false,
+                   int64_t block_req = 0, int64_t halo_req = 0);
+bool generic_is_blocked(const GenericDev *g);
+void generic_geometry(const GenericDev *g, int64_t *block, int64_t *halo, int64_t *nblocks);
+int generic_diagnostics(GenericDev *g, hipStream_t st, int64_t diag[8]);
+int64_t blocked_min_samples();
 int generic_set_model(GenericDev *g, const HostModel &m);
 void generic_destroy(GenericDev *g);
 int64_t generic_workspace_bytes(const GenericDev *g);

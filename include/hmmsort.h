@@ -56,6 +56,8 @@ typedef struct hmm_trans {
 #define HMMSORT_ENGINE_STRICT 1 /* generic engine: one sequential sweep per signal in the
                                    reference's operation order (bit-exact Viterbi incl. ll) */
 #define HMMSORT_ENGINE_RING 2   /* time-parallel ring engine or fail with HMMSORT_EUNSUP */
+#define HMMSORT_ENGINE_BLOCKED 3 /* any transition list (overlap models): the strict recursion run
+                                    time-parallel over blocks with a certified warm-up */
 
 const char *hmmsort_last_error(void);
 int hmmsort_version(void);

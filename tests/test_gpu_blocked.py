@@ -1,0 +1,108 @@
+"""Blocked engine (csrc/generic_blocked.hip): the strict Viterbi recursion run time-parallel over an
+arbitrary transition list -- the overlap-resolving models of reference types.jl:78-90 that the
+reference's decode path uses (hmmsort.jl:54, test/runtests.jl:24).  Bar: path bit-identical to the
+oracle, ll within 1e-9 relative (per-block partial sums are combined in a different order)."""
+import numpy as np
+import pytest
+
+from conftest import to_oracle_sm
+
+pytestmark = pytest.mark.gpu
+LL_RTOL = 1e-9
+
+
+@pytest.fixture(autouse=True)
+def _engine(H):
+    H.set_option("engine", H.ENGINE_BLOCKED)
+    H.set_option("block", 0)
+    H.set_option("halo", 0)
+    yield
+    H.set_option("engine", H.ENGINE_AUTO)
+    H.set_option("block", 0)
+    H.set_option("halo", 0)
+    H.set_option("escalate", 1)
+
+
+def _templates(H, K, n):
+    par = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)][:n]
+    return np.asfortranarray(np.stack([H.create_spike_template(K, a, b, c) for a, b, c in par], 1))
+
+
+def _check(O, H, y, sm, temps, sigma):
+    x, ll = H.viterbi(y, sm, temps, sigma)
+    xo, llo = O.viterbi(y, to_oracle_sm(O, sm), temps, sigma)
+    assert np.array_equal(x, xo)
+    assert abs(ll - llo) <= LL_RTOL * abs(llo)
+    return x
+
+
+def test_reference_viterbi_test_shape(O, H):
+    # test/runtests.jl:17-34: two templates, K=60, overlaps on (3600 states), 20 000 samples
+    temps = _templates(H, 60, 2)
+    pp = [0.003, 0.001]
+    sm = H.StateMatrix.create(2, 60, np.log(pp), True)
+    y = H.create_signal(20000, 0.3, pp, temps, seed=11)
+    y[5000:5060] += temps[:, 0]; y[5020:5080] += temps[:, 1]      # an overlapping pair
+    x = _check(O, H, y, sm, temps, 0.3)
+    assert H.get_option("last_escalations") == 0
+    assert x.max() > 1 + 2 * 59                                      # pair states decoded
+    # AUTO picks the blocked engine for overlap models of this length
+    H.set_option("engine", H.ENGINE_AUTO)
+    from hmmsort_amd import device
+    p = device.Plan(len(y), sm, temps, 0.3)
+    info = p.info()
+    assert info["engine"] == H.ENGINE_BLOCKED and info["nchains"] > 1 and info["halo"] >= 256
+    p.close()
+
+
+@pytest.mark.parametrize("N,K,T", [(3, 20, 30011), (2, 33, 4097), (4, 12, 25000)])
+def test_overlap_shapes(O, H, N, K, T):
+    temps = _templates(H, K, N)
+    pp = [0.01, 0.006, 0.008, 0.005][:N]
+    sm = H.StateMatrix.create(N, K, np.log(pp), True)
+    y = H.create_signal(T, 0.3, pp, temps, seed=5 + N)
+    _check(O, H, y, sm, temps, 0.3)
+    assert H.get_option("last_escalations") == 0
+
+
+def test_ring_model_through_blocked_engine(O, H):
+    temps = _templates(H, 40, 2)
+    pp = [0.01, 0.005]
+    sm = H.StateMatrix.create(2, temps.shape[0], np.log(pp), False)
+    y = H.create_signal(50000, 0.3, pp, temps, seed=3)
+    _check(O, H, y, sm, temps, 0.3)
+
+
+def test_short_blocks_and_ragged_tail(O, H):
+    temps = _templates(H, 16, 2)
+    pp = [0.01, 0.01]
+    sm = H.StateMatrix.create(2, 16, np.log(pp), True)
+    y = H.create_signal(6000 + 37, 0.3, pp, temps, seed=9)
+    H.set_option("block", 128)
+    H.set_option("halo", 128)
+    _check(O, H, y, sm, temps, 0.3)
+
+
+def test_warmup_too_short_is_flagged_and_escalated(O, H):
+    temps = _templates(H, 60, 2)
+    pp = [0.02, 0.02]
+    sm = H.StateMatrix.create(2, 60, np.log(pp), True)
+    y = H.create_signal(20000, 0.3, pp, temps, seed=13)
+    H.set_option("block", 256)
+    H.set_option("halo", 64)          # shorter than one spike: the certificate must notice
+    H.set_option("engine", H.ENGINE_AUTO)
+    xo, llo = O.viterbi(y, to_oracle_sm(O, sm), temps, 0.3)
+    x, ll = H.viterbi(y, sm, temps, 0.3)
+    assert H.get_option("last_escalations") >= 1
+    assert np.array_equal(x, xo) and abs(ll - llo) <= LL_RTOL * abs(llo)
+    from hmmsort_amd import device
+    import torch
+    p = device.Plan(len(y), sm, temps, 0.3)
+    dy = torch.from_numpy(y).cuda()
+    dx = torch.zeros(len(y), dtype=torch.int16, device="cuda")
+    dll = torch.zeros(1, dtype=torch.float64, device="cuda")
+    p.viterbi(dy, dx, dll)
+    torch.cuda.synchronize()
+    d = p.diagnostics()
+    assert d[0] > 0 and d[2] > 1e-6
+    p.close()
