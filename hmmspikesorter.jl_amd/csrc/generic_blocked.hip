@@ -44,106 +44,166 @@ struct BlockArgs {
     const int32_t *tinfo; // [S] tail offset << 8 | tail count (incoming transitions after the first)
     const int32_t *tsrc;  // [ntail]
     const double *tlp;    // [ntail]
-    int ntail, tail_lds;
-    double c0, den;
+    int ntail;
+    double c0, den, rden;  // rden = RN(1/den)
     int16_t *T2;
     double *endv, *warmv; // [nblk][S]
     double *gbuf;         // [nblk][2S] when the columns do not fit LDS, else null
 };
 
-// One workgroup = one block.  SPT = states per thread; CACHE keeps the per-state constants in
-// registers, otherwise they are re-read (coalesced, L2-resident) every sample.
-template <int SPT, bool CACHE>
+// (dd*dd)/den correctly rounded without the division sequence: with r = RN(1/den) from the host,
+// q = RN(x*r), then q + RN(x - q*den)*r in one fma is the correctly rounded quotient (Markstein's
+// theorem; x and den are normal and far from the exponent limits here).  Same double as utils.jl:4.
+__device__ __forceinline__ double funcl_m(double x, double mu, double c0, double den, double rden)
+{
+    const double dd = x - mu;
+    const double sq = dd * dd;
+    const double q = sq * rden;
+    const double rem = __builtin_fma(-q, den, sq);
+    return c0 - __builtin_fma(rem, rden, q);
+}
+
+// Barrier that orders LDS traffic only: the back-pointer stores of the previous sample stay in
+// flight (a __syncthreads() would drain them to L2 every sample, which is what bounds the sweep).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// the incoming transitions after the first one (multi-source states only): viterbi.jl:76-84
+template <typename PrevPtr, typename SrcPtr, typename LpPtr>
+__device__ __forceinline__ void block_tail(PrevPtr prev, int ti, SrcPtr tsrc, LpPtr tlp,
+                                           double &best, int &arg)
+{
+    const int tn = ti & 255;
+    int tp = ti >> 8;
+    for (int k = 0; k < tn; k++, tp++) {
+        const int sq = tsrc[tp];
+        const double tt = prev[sq] + tlp[tp];
+        if (tt > best) { best = tt; arg = sq + 1; }  // :80 strict, list order
+    }
+}
+
+// One workgroup = one block.  With SPT > 0 every thread keeps the constants of its SPT states in
+// registers (S <= 4096); SPT = 0 re-reads them each sample (coalesced, L2-resident).  GCOL: the
+// two trellis columns live in global memory (S too large for LDS); TLDS: tails staged in LDS.
+// Address spaces are fixed at compile time so that column accesses are ds_* (not flat) operations.
+template <int SPT, bool GCOL, bool TLDS>
 __global__ __launch_bounds__(1024) void gen_vit_block(BlockArgs a)
 {
     extern __shared__ double sh[];
+    constexpr bool CACHE = SPT > 0;
+    constexpr int NS = CACHE ? SPT : 1;
     const int c = blockIdx.x, S = a.S, tid = threadIdx.x, nt = blockDim.x;
-    double *prev = a.gbuf ? a.gbuf + (int64_t)c * 2 * S : sh;
-    double *cur = prev + S;
-    const int32_t *tsrc = a.tsrc;
-    const double *tlp = a.tlp;
-    if (a.tail_lds) {
-        double *l_tlp = sh + (a.gbuf ? 0 : 2 * S);
-        int32_t *l_tsrc = (int32_t *)(l_tlp + a.ntail);
+    double *l_tlp = sh + (GCOL ? 0 : 2 * S);
+    int32_t *l_tsrc = (int32_t *)(l_tlp + a.ntail);
+    if (TLDS)
         for (int i = tid; i < a.ntail; i += nt) { l_tlp[i] = a.tlp[i]; l_tsrc[i] = a.tsrc[i]; }
-        tsrc = l_tsrc; tlp = l_tlp;
-    }
     const int64_t s = (int64_t)c * a.B;
     const int64_t e = (s + a.B < a.T) ? s + a.B : a.T;
     const int64_t w = (s - a.H > 0) ? s - a.H : 0;
-    const double c0 = a.c0, den = a.den;
+    const double c0 = a.c0, den = a.den, rden = a.rden;
+    double *warm = a.warmv + (int64_t)c * S;
+    double *gcol = GCOL ? a.gbuf + (int64_t)c * 2 * S : nullptr;
 
-    double mean_r[SPT], lp0_r[SPT];
-    int src0_r[SPT], ti_r[SPT];
+    double mean_r[NS], lp0_r[NS];
+    int src0_r[NS], ti_r[NS];
     if (CACHE) {
 #pragma unroll
-        for (int i = 0; i < SPT; i++) {
-            const int j = tid + i * nt;
-            const bool ok = j < S;
-            mean_r[i] = ok ? a.mean[j] : 0.0;
-            lp0_r[i] = ok ? a.lp0[j] : 0.0;
-            src0_r[i] = ok ? a.src0[j] : 0;
-            ti_r[i] = ok ? a.tinfo[j] : 0;
+        for (int i = 0; i < NS; i++) {
+            const int j = tid + i * nt < S ? tid + i * nt : S - 1;
+            mean_r[i] = a.mean[j];
+            lp0_r[i] = a.lp0[j];
+            src0_r[i] = a.src0[j];
+            ti_r[i] = a.tinfo[j];
         }
     }
+    int par = 0;  // cur = column par, prev = column par ^ 1
     {   // first column: viterbi.jl:55-63 at the start of the signal, flat (emissions) elsewhere
         const double y0 = a.y[w];
-#pragma unroll
-        for (int i = 0; i < SPT; i++) {
-            const int j = tid + i * nt;
-            if (j < S) {
-                const double m = CACHE ? mean_r[i] : a.mean[j];
-                cur[j] = (w == 0 && j == 0) ? 0.0 : funcl_b(y0, m, c0, den);
-                if (s == 0) a.T2[j] = 1;
-            }
-        }
-        if (s > 0 && w == s - 1) {
-#pragma unroll
-            for (int i = 0; i < SPT; i++) {
-                const int j = tid + i * nt;
-                if (j < S) a.warmv[(int64_t)c * S + j] = cur[j];
-            }
+        for (int j = tid; j < S; j += nt) {
+            const double v = (w == 0 && j == 0) ? 0.0 : funcl_m(y0, a.mean[j], c0, den, rden);
+            if (GCOL) gcol[j] = v; else sh[j] = v;
+            if (s == 0) a.T2[j] = 1;
+            if (s > 0 && w == s - 1) warm[j] = v;
         }
     }
     for (int64_t t = w + 1; t < e; t++) {
-        __threadfence_block();
-        __syncthreads();
-        double *tmp = prev; prev = cur; cur = tmp;
+        if (GCOL) { __threadfence_block(); __syncthreads(); }
+        else lds_barrier();
+        par ^= 1;
         const double yt = a.y[t];
-        const bool own = t >= s;
+        const bool own = t >= s, at_warm = t == s - 1;
         int16_t *psi = a.T2 + (int64_t)S * t;
+        if (CACHE) {  // columns in LDS
+            const double *prev = sh + (par ^ 1) * S;
+            double *cur = sh + par * S;
+            double best[NS];
+            int arg[NS];
 #pragma unroll
-        for (int i = 0; i < SPT; i++) {
-            const int j = tid + i * nt;
-            if (j < S) {
-                const double m = CACHE ? mean_r[i] : a.mean[j];
-                const double l0 = CACHE ? lp0_r[i] : a.lp0[j];
-                const int s0 = CACHE ? src0_r[i] : a.src0[j];
-                const int ti = CACHE ? ti_r[i] : a.tinfo[j];
-                double best = -INFINITY;  // viterbi.jl:52
-                int arg = 1;              // viterbi.jl:53
-                double tt = prev[s0] + l0;  // :79
-                if (tt > best) { best = tt; arg = s0 + 1; }  // :80 strict, list order
-                const int tn = ti & 255;
-                int tp = ti >> 8;
-                for (int q = 0; q < tn; q++, tp++) {
-                    const int sq = tsrc[tp];
-                    tt = prev[sq] + tlp[tp];
-                    if (tt > best) { best = tt; arg = sq + 1; }
+            for (int i = 0; i < NS; i++) {
+                const double tt = prev[src0_r[i]] + lp0_r[i];  // :79
+                const bool up = tt > -INFINITY;                // :80 against fill(-Inf)
+                best[i] = up ? tt : -INFINITY;
+                arg[i] = up ? src0_r[i] + 1 : 1;
+            }
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                if (ti_r[i] & 255) {
+                    if (TLDS) block_tail(prev, ti_r[i], l_tsrc, l_tlp, best[i], arg[i]);
+                    else block_tail(prev, ti_r[i], a.tsrc, a.tlp, best[i], arg[i]);
                 }
-                const double v = best + funcl_b(yt, m, c0, den);  // :85-87
-                cur[j] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                const int j = tid + i * nt;
+                const double v = best[i] + funcl_m(yt, mean_r[i], c0, den, rden);  // :85-87
+                if (j < S) {
+                    cur[j] = v;
+                    if (own) psi[j] = (int16_t)arg[i];
+                    if (at_warm) warm[j] = v;
+                }
+            }
+        } else {
+#pragma unroll 2
+            for (int j = tid; j < S; j += nt) {
+                const int s0 = a.src0[j], ti = a.tinfo[j];
+                const double l0 = a.lp0[j], q = funcl_m(yt, a.mean[j], c0, den, rden);
+                double v;
+                int arg;
+                if (GCOL) {
+                    const double *prev = gcol + (par ^ 1) * S;
+                    const double tt = prev[s0] + l0;
+                    const bool up = tt > -INFINITY;
+                    double best = up ? tt : -INFINITY;
+                    arg = up ? s0 + 1 : 1;
+                    if (ti & 255) {
+                        if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg);
+                        else block_tail(prev, ti, a.tsrc, a.tlp, best, arg);
+                    }
+                    v = best + q;
+                    gcol[par * S + j] = v;
+                } else {
+                    const double *prev = sh + (par ^ 1) * S;
+                    const double tt = prev[s0] + l0;
+                    const bool up = tt > -INFINITY;
+                    double best = up ? tt : -INFINITY;
+                    arg = up ? s0 + 1 : 1;
+                    if (ti & 255) {
+                        if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg);
+                        else block_tail(prev, ti, a.tsrc, a.tlp, best, arg);
+                    }
+                    v = best + q;
+                    sh[par * S + j] = v;
+                }
                 if (own) psi[j] = (int16_t)arg;
-                if (t == s - 1) a.warmv[(int64_t)c * S + j] = v;
+                if (at_warm) warm[j] = v;
             }
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < SPT; i++) {
-        const int j = tid + i * nt;
-        if (j < S) a.endv[(int64_t)c * S + j] = cur[j];
-    }
+    for (int j = tid; j < S; j += nt)
+        a.endv[(int64_t)c * S + j] = GCOL ? gcol[par * S + j] : sh[par * S + j];
 }
 
 // Boundary certificate: spread over the states of (warm column of block c) - (end column of block
@@ -441,14 +501,14 @@ void blocked_destroy(GenericDev *g)
         if (p) (void)hipFree(p);
 }
 
-template <int SPT, bool CACHE>
+template <int SPT, bool GCOL, bool TLDS>
 static int launch_block_sweep(GenericDev *g, const BlockArgs &a, int threads, size_t lds,
                               hipStream_t st)
 {
     if (lds > 64 * 1024)
-        HS_HIP(hipFuncSetAttribute((const void *)gen_vit_block<SPT, CACHE>,
+        HS_HIP(hipFuncSetAttribute((const void *)gen_vit_block<SPT, GCOL, TLDS>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((gen_vit_block<SPT, CACHE>), dim3((unsigned)g->nblk), dim3(threads), lds, st, a);
+    hipLaunchKernelGGL((gen_vit_block<SPT, GCOL, TLDS>), dim3((unsigned)g->nblk), dim3(threads), lds, st, a);
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }
@@ -466,9 +526,10 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     BlockArgs a;
     a.y = d_y; a.T = T; a.S = (int)S; a.B = (int)g->B; a.H = (int)g->H;
     a.mean = g->d_mean; a.lp0 = g->d_lp0; a.src0 = g->d_src0; a.tinfo = g->d_tinfo;
-    a.tsrc = g->d_tsrc; a.tlp = g->d_tlp; a.ntail = g->ntail; a.tail_lds = g->blk_tail_lds;
+    a.tsrc = g->d_tsrc; a.tlp = g->d_tlp; a.ntail = g->ntail;
     a.c0 = -kLog2Pi - g->lsig;
     a.den = 2.0 * (g->sigma * g->sigma);
+    a.rden = 1.0 / a.den;
     a.T2 = g->d_T2; a.endv = g->d_endv; a.warmv = g->d_warmv;
     a.gbuf = g->blk_cols_lds ? nullptr : g->d_blkbuf;
     size_t lds = (g->blk_cols_lds ? 2 * S * 8 : 0) + (g->blk_tail_lds ? (size_t)g->ntail * 12 + 8 : 0);
@@ -476,14 +537,14 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     const int spt = (int)((S + threads - 1) / threads);
     HS_HIP(hipMemsetAsync(g->d_bdiag, 0, 8 * sizeof(unsigned long long), st));
     int rc;
-    if (spt <= 1) rc = launch_block_sweep<1, true>(g, a, threads, lds, st);
-    else if (spt <= 2) rc = launch_block_sweep<2, true>(g, a, threads, lds, st);
-    else if (spt <= 4) rc = launch_block_sweep<4, true>(g, a, threads, lds, st);
-    else if (spt <= 8) rc = launch_block_sweep<8, true>(g, a, threads, lds, st);
-    else if (spt <= 12) rc = launch_block_sweep<12, true>(g, a, threads, lds, st);
-    else if (spt <= 16) rc = launch_block_sweep<16, false>(g, a, threads, lds, st);
-    else if (spt <= 24) rc = launch_block_sweep<24, false>(g, a, threads, lds, st);
-    else rc = launch_block_sweep<32, false>(g, a, threads, lds, st);
+    const bool gcol = !g->blk_cols_lds, tl = g->blk_tail_lds;
+    if (!gcol && tl && spt <= 1) rc = launch_block_sweep<1, false, true>(g, a, threads, lds, st);
+    else if (!gcol && tl && spt <= 2) rc = launch_block_sweep<2, false, true>(g, a, threads, lds, st);
+    else if (!gcol && tl && spt <= 4) rc = launch_block_sweep<4, false, true>(g, a, threads, lds, st);
+    else if (!gcol && tl) rc = launch_block_sweep<0, false, true>(g, a, threads, lds, st);
+    else if (!gcol) rc = launch_block_sweep<0, false, false>(g, a, threads, lds, st);
+    else if (tl) rc = launch_block_sweep<0, true, true>(g, a, threads, lds, st);
+    else rc = launch_block_sweep<0, true, false>(g, a, threads, lds, st);
     if (rc) return rc;
     const int nb = (int)g->nblk;
     if (nb > 1) {

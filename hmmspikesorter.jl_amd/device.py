@@ -36,7 +36,11 @@ class Plan:
             lib().hmmsort_plan_destroy(self._h)
             self._h = C.c_void_p(None)
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def info(self):
         v = [C.c_int64(0) for _ in range(5)]
