@@ -17,8 +17,11 @@
 // and k_block_finish fills the unmerged heads.  ll (viterbi.jl:92-96) is re-accumulated along the
 // decoded path per block with the reference's op order and combined across blocks.
 //
-// HBM layout: T2 S x T int16 column-major as in the strict engine; per-block columns endv/warmv
-// nblk x S doubles; maps nblk x S int16.
+// HBM layout: back-pointers are kept only for the nms states with more than one incoming transition
+// (T2c, nms x T int16; 236 of 3600 states at N=2, K=60): a single-source state's pointer is its
+// source whenever its value is finite, and the backtrace only visits finite values (columns of all
+// -Inf/NaN, i.e. non-finite data, are the one case where this differs from viterbi.jl:53's
+// ones()).  Per-block columns endv/warmv nblk x S doubles; maps nblk x S int16.
 #include <cmath>
 
 #include "generic_dev.h"
@@ -34,6 +37,11 @@ __device__ __forceinline__ double funcl_b(double x, double mu, double c0, double
     return c0 - (dd * dd) / den;  // utils.jl:4 with the invariants hoisted (see generic_engine.hip)
 }
 
+struct MsRec {  // constants of one multi-source state, phase B of the sweep
+    double lp0, mean;
+    int32_t j, s0, ti, pad;
+};
+
 struct BlockArgs {
     const double *y;
     int64_t T;
@@ -45,8 +53,10 @@ struct BlockArgs {
     const int32_t *tsrc;  // [ntail]
     const double *tlp;    // [ntail]
     int ntail;
+    const MsRec *ms;      // [nms] states with more than one incoming transition
+    int nms;
     double c0, den, rden;  // rden = RN(1/den)
-    int16_t *T2;
+    int16_t *T2c;         // [T][nms]
     double *endv, *warmv; // [nblk][S]
     double *gbuf;         // [nblk][2S] when the columns do not fit LDS, else null
 };
@@ -118,85 +128,97 @@ __global__ __launch_bounds__(1024) void gen_vit_block(BlockArgs a)
             ti_r[i] = a.tinfo[j];
         }
     }
+    int ms_j = 0, ms_s0 = 0, ms_ti = 0;  // this thread's multi-source state (phase B)
+    double ms_l0 = 0.0, ms_mean = 0.0;
+    if (CACHE && tid < a.nms) {
+        const MsRec r = a.ms[tid];
+        ms_j = r.j; ms_s0 = r.s0; ms_ti = r.ti; ms_l0 = r.lp0; ms_mean = r.mean;
+    }
     int par = 0;  // cur = column par, prev = column par ^ 1
     {   // first column: viterbi.jl:55-63 at the start of the signal, flat (emissions) elsewhere
         const double y0 = a.y[w];
         for (int j = tid; j < S; j += nt) {
             const double v = (w == 0 && j == 0) ? 0.0 : funcl_m(y0, a.mean[j], c0, den, rden);
             if (GCOL) gcol[j] = v; else sh[j] = v;
-            if (s == 0) a.T2[j] = 1;
             if (s > 0 && w == s - 1) warm[j] = v;
         }
     }
+    double ynext = a.y[w + 1 < e ? w + 1 : w];
     for (int64_t t = w + 1; t < e; t++) {
+        const double yt = ynext;
+        ynext = a.y[t + 1 < e ? t + 1 : t];  // one sample ahead: its latency hides behind this column
         if (GCOL) { __threadfence_block(); __syncthreads(); }
         else lds_barrier();
         par ^= 1;
-        const double yt = a.y[t];
         const bool own = t >= s, at_warm = t == s - 1;
-        int16_t *psi = a.T2 + (int64_t)S * t;
+        int16_t *psi = a.T2c + (int64_t)a.nms * t;
         if (CACHE) {  // columns in LDS
             const double *prev = sh + (par ^ 1) * S;
             double *cur = sh + par * S;
-            double best[NS];
-            int arg[NS];
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                const double tt = prev[src0_r[i]] + lp0_r[i];  // :79
-                const bool up = tt > -INFINITY;                // :80 against fill(-Inf)
-                best[i] = up ? tt : -INFINITY;
-                arg[i] = up ? src0_r[i] + 1 : 1;
-            }
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                if (ti_r[i] & 255) {
-                    if (TLDS) block_tail(prev, ti_r[i], l_tsrc, l_tlp, best[i], arg[i]);
-                    else block_tail(prev, ti_r[i], a.tsrc, a.tlp, best[i], arg[i]);
-                }
-            }
+            // phase A: every state's first transition, branch-free; multi-source states (ti != 0)
+            // are finished in phase B by the leading waves, so that the other waves never diverge
 #pragma unroll
             for (int i = 0; i < NS; i++) {
                 const int j = tid + i * nt;
-                const double v = best[i] + funcl_m(yt, mean_r[i], c0, den, rden);  // :85-87
-                if (j < S) {
-                    cur[j] = v;
-                    if (own) psi[j] = (int16_t)arg[i];
+                const double tt = prev[src0_r[i]] + lp0_r[i];  // :79
+                const bool up = tt > -INFINITY;                // :80 against fill(-Inf)
+                const double v = (up ? tt : -INFINITY) + funcl_m(yt, mean_r[i], c0, den, rden);
+                if (j < S && (ti_r[i] & 255) == 0) {
+                    cur[j] = v;                                // :85-87
                     if (at_warm) warm[j] = v;
                 }
             }
+            for (int m = tid; m < a.nms; m += nt) {
+                MsRec r;
+                if (m != tid) r = a.ms[m];
+                const int j = (m == tid) ? ms_j : r.j;
+                const int s0 = (m == tid) ? ms_s0 : r.s0;
+                const double l0 = (m == tid) ? ms_l0 : r.lp0;
+                const double tt = prev[s0] + l0;
+                const bool up = tt > -INFINITY;
+                double best = up ? tt : -INFINITY;
+                int arg = up ? s0 + 1 : 1;
+                const int ti = (m == tid) ? ms_ti : r.ti;
+                if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg);
+                else block_tail(prev, ti, a.tsrc, a.tlp, best, arg);
+                const double v = best + funcl_m(yt, (m == tid) ? ms_mean : r.mean, c0, den, rden);
+                cur[j] = v;
+                if (own) psi[m] = (int16_t)arg;
+                if (at_warm) warm[j] = v;
+            }
         } else {
+            // same two phases with the constants re-read every sample
+            const double *prevl = sh + (par ^ 1) * S;
+            const double *prevg = GCOL ? gcol + (par ^ 1) * S : nullptr;
 #pragma unroll 2
             for (int j = tid; j < S; j += nt) {
                 const int s0 = a.src0[j], ti = a.tinfo[j];
                 const double l0 = a.lp0[j], q = funcl_m(yt, a.mean[j], c0, den, rden);
-                double v;
-                int arg;
-                if (GCOL) {
-                    const double *prev = gcol + (par ^ 1) * S;
-                    const double tt = prev[s0] + l0;
-                    const bool up = tt > -INFINITY;
-                    double best = up ? tt : -INFINITY;
-                    arg = up ? s0 + 1 : 1;
-                    if (ti & 255) {
-                        if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg);
-                        else block_tail(prev, ti, a.tsrc, a.tlp, best, arg);
-                    }
-                    v = best + q;
-                    gcol[par * S + j] = v;
-                } else {
-                    const double *prev = sh + (par ^ 1) * S;
-                    const double tt = prev[s0] + l0;
-                    const bool up = tt > -INFINITY;
-                    double best = up ? tt : -INFINITY;
-                    arg = up ? s0 + 1 : 1;
-                    if (ti & 255) {
-                        if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg);
-                        else block_tail(prev, ti, a.tsrc, a.tlp, best, arg);
-                    }
-                    v = best + q;
-                    sh[par * S + j] = v;
+                const double tt = (GCOL ? prevg[s0] : prevl[s0]) + l0;
+                const double v = (tt > -INFINITY ? tt : -INFINITY) + q;
+                if ((ti & 255) == 0) {
+                    if (GCOL) gcol[par * S + j] = v; else sh[par * S + j] = v;
+                    if (at_warm) warm[j] = v;
                 }
-                if (own) psi[j] = (int16_t)arg;
+            }
+            for (int m = tid; m < a.nms; m += nt) {
+                const MsRec r = a.ms[m];
+                const int j = r.j, s0 = r.s0, ti = r.ti;
+                const double l0 = r.lp0, q = funcl_m(yt, r.mean, c0, den, rden);
+                const double tt = (GCOL ? prevg[s0] : prevl[s0]) + l0;
+                const bool up = tt > -INFINITY;
+                double best = up ? tt : -INFINITY;
+                int arg = up ? s0 + 1 : 1;
+                if (GCOL) {
+                    if (TLDS) block_tail(prevg, ti, l_tsrc, l_tlp, best, arg);
+                    else block_tail(prevg, ti, a.tsrc, a.tlp, best, arg);
+                } else {
+                    if (TLDS) block_tail(prevl, ti, l_tsrc, l_tlp, best, arg);
+                    else block_tail(prevl, ti, a.tsrc, a.tlp, best, arg);
+                }
+                const double v = best + q;
+                if (GCOL) gcol[par * S + j] = v; else sh[par * S + j] = v;
+                if (own) psi[m] = (int16_t)arg;
                 if (at_warm) warm[j] = v;
             }
         }
@@ -247,88 +269,140 @@ __global__ __launch_bounds__(256) void k_block_check(const double *__restrict__ 
     }
 }
 
-// All S end states of block c walked back to its first sample.  fmap[c][j] = state at sample
-// c*B-1 when sample e-1 is in state j+1 (block 0: unused).  Once every walker sits in the same
-// state the rest of the block's path is known: it is written to x and merged[c] records the last
-// sample written (c*B-1 when nothing was).
-__global__ __launch_bounds__(256) void k_block_map(const int16_t *__restrict__ T2, int64_t T, int S,
-                                                   int B, int16_t *__restrict__ fmap,
+// Back-pointer lookup.  bt[j] > 0: the only source of state j+1; bt[j] <= 0: minus the index of
+// state j+1 among the stored pointers of a sample (a row of T2c).
+__device__ __forceinline__ int back_step(const int32_t *bt, const int16_t *row, int v)
+{
+    const int code = bt[v - 1];
+    return code > 0 ? code : (int)row[-code];
+}
+
+// All S end states of block c walked back to its first sample, rows of T2c staged through LDS W at
+// a time.  Once every walker sits in the same state the rest of the block's path is known: thread 0
+// writes it to x and merged[c] records the last sample written (c*B-1 when nothing was).
+// fconst[c] = state at sample c*B-1 when it no longer depends on the end state (-1 otherwise, then
+// fmap[c][j] holds it for end state j+1).  Block 0 has no predecessor: fconst[0] = 1, unused.
+__global__ __launch_bounds__(256) void k_block_map(const int16_t *__restrict__ T2c,
+                                                   const int32_t *__restrict__ btg, int nms, int W,
+                                                   int bt_lds, int64_t T, int S, int B,
+                                                   int16_t *__restrict__ fmap,
+                                                   int16_t *__restrict__ fconst,
                                                    int64_t *__restrict__ merged,
                                                    int16_t *__restrict__ x)
 {
-    extern __shared__ int16_t wk[];  // S walkers
+    extern __shared__ int16_t lds16[];
     __shared__ int mn, mx;
+    int16_t *wk = lds16;                                  // S walkers
+    int16_t *rows = wk + ((S + 3) & ~3);                  // W staged rows
+    int32_t *btl = (int32_t *)(rows + ((W * nms + 3) & ~3));
     const int c = blockIdx.x, tid = threadIdx.x;
     const int64_t s = (int64_t)c * B;
     const int64_t e = (s + B < T) ? s + B : T;
+    if (bt_lds)
+        for (int j = tid; j < S; j += 256) btl[j] = btg[j];
+    const int32_t *bt = bt_lds ? btl : btg;
     for (int j = tid; j < S; j += 256) wk[j] = (int16_t)(j + 1);
-    int64_t t = e - 1;  // walkers hold the state at sample t
     bool one = (S == 1);
-    int step = 0;
-    while (t > s && !one) {
-        const int16_t *psi = T2 + (int64_t)S * t;
-        for (int j = tid; j < S; j += 256) wk[j] = psi[wk[j] - 1];
-        t--;
-        if ((++step & 15) == 0) {
+    int cur = 1;              // thread 0: the merged walker
+    int64_t mrg = s - 1;      // last sample written to x
+    if (one && tid == 0 && e - 1 >= s) { mrg = e - 1; x[e - 1] = 1; }
+    // row r maps the state at sample r to the state at sample r-1
+    for (int64_t hi = e - 1; hi >= s + 1; hi -= W) {
+        const int64_t lo = (hi - W + 1 > s + 1) ? hi - W + 1 : s + 1;
+        const int n = (int)(hi - lo + 1);
+        __syncthreads();
+        const int16_t *src = T2c + (int64_t)nms * lo;
+        for (int i = tid; i < n * nms; i += 256) rows[i] = src[i];
+        __syncthreads();
+        if (!one) {
+            for (int j = tid; j < S; j += 256) {
+                int v = wk[j];
+                for (int r = n - 1; r >= 0; r--) v = back_step(bt, rows + r * nms, v);
+                wk[j] = (int16_t)v;
+            }
             if (tid == 0) { mn = 32767; mx = 0; }
             __syncthreads();
-            int lo = 32767, hi = 0;
+            int l = 32767, h = 0;
             for (int j = tid; j < S; j += 256) {
                 const int v = wk[j];
-                lo = v < lo ? v : lo;
-                hi = v > hi ? v : hi;
+                l = v < l ? v : l;
+                h = v > h ? v : h;
             }
-            atomicMin(&mn, lo);
-            atomicMax(&mx, hi);
+            atomicMin(&mn, l);
+            atomicMax(&mx, h);
             __syncthreads();
             one = (mn == mx);
-            __syncthreads();
+            if (one && tid == 0) {  // all walkers agree on the state at sample lo-1
+                cur = wk[0];
+                mrg = lo - 1;
+                x[lo - 1] = (int16_t)cur;
+            }
+        } else if (tid == 0) {
+            for (int r = n - 1; r >= 0; r--) {
+                cur = back_step(bt, rows + r * nms, cur);
+                x[lo + r - 1] = (int16_t)cur;
+            }
         }
     }
     __syncthreads();
+    // walkers (or cur) now hold the state at sample s; one more row reaches the previous block
+    const int16_t *row_s = T2c + (int64_t)nms * s;
     if (one) {
         if (tid == 0) {
-            int v = wk[0];
-            merged[c] = t;
-            x[t] = (int16_t)v;
-            while (t > s) {
-                v = T2[(int64_t)S * t + (v - 1)];
-                t--;
-                x[t] = (int16_t)v;
-            }
-            wk[0] = (int16_t)((c > 0) ? T2[(int64_t)S * s + (v - 1)] : 1);
+            merged[c] = mrg;
+            fconst[c] = (int16_t)((c > 0) ? back_step(bt, row_s, cur) : 1);
         }
-        __syncthreads();
-        const int16_t f = wk[0];
-        __syncthreads();
-        for (int j = tid; j < S; j += 256) fmap[(int64_t)c * S + j] = f;
     } else {
-        if (tid == 0) merged[c] = s - 1;
-        const int16_t *psi = T2 + (int64_t)S * s;
-        for (int j = tid; j < S; j += 256)
-            fmap[(int64_t)c * S + j] = (c > 0) ? psi[wk[j] - 1] : (int16_t)1;
+        if (tid == 0) { merged[c] = s - 1; fconst[c] = (int16_t)((c > 0) ? -1 : 1); }
+        if (c > 0)
+            for (int j = tid; j < S; j += 256)
+                fmap[(int64_t)c * S + j] = (int16_t)back_step(bt, row_s, wk[j]);
     }
 }
 
 // argmax of the last column (first maximum, viterbi.jl:90), then the end state of every block
-__global__ void k_block_compose(const double *__restrict__ endv, const int16_t *__restrict__ fmap,
-                                int S, int nblk, int16_t *__restrict__ endstate)
+__global__ __launch_bounds__(256) void k_block_compose(const double *__restrict__ endv,
+                                                       const int16_t *__restrict__ fmap,
+                                                       const int16_t *__restrict__ fconst, int S,
+                                                       int nblk, int16_t *__restrict__ endstate)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ double bv[256];
+    __shared__ int bi[256];
+    const int tid = threadIdx.x;
     const double *last = endv + (int64_t)(nblk - 1) * S;
-    int best = 0;
-    for (int j = 1; j < S; j++)
-        if (last[j] > last[best]) best = j;
-    int v = best + 1;
-    endstate[nblk - 1] = (int16_t)v;
-    for (int c = nblk - 1; c >= 1; c--) {
-        v = fmap[(int64_t)c * S + (v - 1)];
-        endstate[c - 1] = (int16_t)v;
+    double v = -INFINITY;
+    int idx = S;  // first maximum = smallest index among the largest values; NaN never wins (:90)
+    for (int j = tid; j < S; j += 256) {
+        const double a = last[j];
+        if (idx == S ? a == a : a > v) { v = a; idx = j; }
+    }
+    bv[tid] = v; bi[tid] = idx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const double a = bv[tid + o];
+            const int ia = bi[tid + o];
+            if (ia < S && (bi[tid] == S || a > bv[tid] || (a == bv[tid] && ia < bi[tid]))) {
+                bv[tid] = a; bi[tid] = ia;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        // the reference's scan starts at state 1 and only moves on a strict '>': a NaN there stays
+        int st = (bi[0] < S && last[0] == last[0] ? bi[0] : 0) + 1;
+        endstate[nblk - 1] = (int16_t)st;
+        for (int c = nblk - 1; c >= 1; c--) {
+            const int f = fconst[c];
+            st = f > 0 ? f : fmap[(int64_t)c * S + (st - 1)];
+            endstate[c - 1] = (int16_t)st;
+        }
     }
 }
 
 // the part of each block's path above the merge point
-__global__ void k_block_finish(const int16_t *__restrict__ T2, int64_t T, int S, int B, int nblk,
+__global__ void k_block_finish(const int16_t *__restrict__ T2c, const int32_t *__restrict__ bt,
+                               int nms, int64_t T, int S, int B, int nblk,
                                const int16_t *__restrict__ endstate,
                                const int64_t *__restrict__ merged, int16_t *__restrict__ x)
 {
@@ -341,7 +415,7 @@ __global__ void k_block_finish(const int16_t *__restrict__ T2, int64_t T, int S,
     int64_t t = e - 1;
     if (t >= stop) x[t] = (int16_t)v;
     while (t > stop) {
-        v = T2[(int64_t)S * t + (v - 1)];
+        v = back_step(bt, T2c + (int64_t)nms * t, v);
         t--;
         x[t] = (int16_t)v;
     }
@@ -400,13 +474,21 @@ __global__ __launch_bounds__(256) void k_block_ll(const double *__restrict__ y,
     }
 }
 
-__global__ void k_block_ll_sum(const double *__restrict__ part, int nblk, double *__restrict__ ll)
+__global__ __launch_bounds__(256) void k_block_ll_sum(const double *__restrict__ part, int nblk,
+                                                      double *__restrict__ ll)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    extern __shared__ double sp[];  // 3*nblk when it fits (lds != 0)
+    const bool staged = nblk * 3 * sizeof(double) <= 60 * 1024;
+    if (staged) {
+        for (int i = threadIdx.x; i < 3 * nblk; i += 256) sp[i] = part[i];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const double *p = staged ? sp : part;
     double off = 0.0, acc = 0.0;
     for (int c = 0; c < nblk; c++) {
-        acc += part[3 * c + 2] * off + part[3 * c + 1];
-        off += part[3 * c];
+        acc += p[3 * c + 2] * off + p[3 * c + 1];
+        off += p[3 * c];
     }
     *ll = acc;
 }
@@ -419,7 +501,7 @@ void blocked_geometry(int64_t T, int64_t L, int64_t block_req, int64_t halo_req,
 {
     int64_t h = halo_req > 0 ? halo_req : std::max<int64_t>(256, 4 * L);
     h = (h + 63) / 64 * 64;
-    int64_t b = block_req > 0 ? block_req : std::max<int64_t>(2 * h, (T + 2047) / 2048);
+    int64_t b = block_req > 0 ? block_req : std::max<int64_t>(2 * h, (T + 1023) / 1024);
     b = (b + 63) / 64 * 64;
     if (b < 64) b = 64;
     *B = b; *H = h; *nblk = (T + b - 1) / b;
@@ -441,7 +523,8 @@ int blocked_set_model(GenericDev *g, const HostModel &m)
 {
     const int64_t S = m.S;
     std::vector<double> lp0(S, -INFINITY), tlp;
-    std::vector<int32_t> src0(S, 0), tinfo(S, 0), tsrc;
+    std::vector<int32_t> src0(S, 0), tinfo(S, 0), tsrc, bt(S, 1);
+    std::vector<MsRec> ms;
     for (int64_t j = 0; j < S; j++) {
         const int b = m.in_ptr[j], e = m.in_ptr[j + 1];
         if (e > b) { lp0[j] = m.in_lp[b]; src0[j] = m.in_src[b]; }
@@ -450,6 +533,11 @@ int blocked_set_model(GenericDev *g, const HostModel &m)
                  "blocked engine: in-degree %d of state %lld too large", nt + 1, (long long)j + 1);
         tinfo[j] = (int32_t)((tsrc.size() << 8) | (unsigned)nt);
         for (int q = b + 1; q < e; q++) { tsrc.push_back(m.in_src[q]); tlp.push_back(m.in_lp[q]); }
+        bt[j] = src0[j] + 1;
+        if (nt > 0) {
+            bt[j] = -(int32_t)ms.size();
+            ms.push_back(MsRec{lp0[j], m.mean[j], (int32_t)j, src0[j], tinfo[j], 0});
+        }
     }
     if (g->ntail < 0) {  // first call: allocate
         g->ntail = (int)tsrc.size();
@@ -457,10 +545,17 @@ int blocked_set_model(GenericDev *g, const HostModel &m)
         if ((rc = dalloc(&g->d_lp0, S, &g->bytes)) || (rc = dalloc(&g->d_src0, S, &g->bytes)) ||
             (rc = dalloc(&g->d_tinfo, S, &g->bytes)) ||
             (rc = dalloc(&g->d_tsrc, tsrc.size(), &g->bytes)) ||
-            (rc = dalloc(&g->d_tlp, tlp.size(), &g->bytes)))
+            (rc = dalloc(&g->d_tlp, tlp.size(), &g->bytes)) ||
+            (rc = dalloc((MsRec **)&g->d_ms, ms.size(), &g->bytes)) ||
+            (rc = dalloc(&g->d_bt, S, &g->bytes)))
             return rc;
+        g->nms = (int)ms.size();
     }
-    HS_CHECK((int)tsrc.size() == g->ntail, HMMSORT_EINVAL, "set_model: transition structure changed");
+    HS_CHECK((int)tsrc.size() == g->ntail && (int)ms.size() == g->nms, HMMSORT_EINVAL,
+             "set_model: transition structure changed");
+    HS_HIP(hipMemcpy(g->d_bt, bt.data(), S * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!ms.empty())
+        HS_HIP(hipMemcpy(g->d_ms, ms.data(), ms.size() * sizeof(MsRec), hipMemcpyHostToDevice));
     HS_HIP(hipMemcpy(g->d_lp0, lp0.data(), S * sizeof(double), hipMemcpyHostToDevice));
     HS_HIP(hipMemcpy(g->d_src0, src0.data(), S * sizeof(int32_t), hipMemcpyHostToDevice));
     HS_HIP(hipMemcpy(g->d_tinfo, tinfo.data(), S * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -485,7 +580,7 @@ int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t
     g->blk_tail_lds = (g->blk_cols_lds ? 2 * S * 8 : 0) + tail_b <= 150 * 1024;
     if ((rc = dalloc(&g->d_endv, nb * S, &g->bytes)) || (rc = dalloc(&g->d_warmv, nb * S, &g->bytes)) ||
         (rc = dalloc(&g->d_fmap, nb * S, &g->bytes)) || (rc = dalloc(&g->d_merged, nb, &g->bytes)) ||
-        (rc = dalloc(&g->d_endstate, nb, &g->bytes)) || (rc = dalloc(&g->d_llpart, 3 * nb, &g->bytes)) ||
+        (rc = dalloc(&g->d_endstate, nb, &g->bytes)) || (rc = dalloc(&g->d_fconst, nb, &g->bytes)) || (rc = dalloc(&g->d_llpart, 3 * nb, &g->bytes)) ||
         (rc = dalloc(&g->d_bdiag, 8, &g->bytes)))
         return rc;
     if (!g->blk_cols_lds && (rc = dalloc(&g->d_blkbuf, nb * 2 * S, &g->bytes))) return rc;
@@ -496,7 +591,7 @@ int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t
 void blocked_destroy(GenericDev *g)
 {
     void *ptrs[] = {g->d_lp0, g->d_src0, g->d_tinfo, g->d_tsrc, g->d_tlp, g->d_endv, g->d_warmv,
-                    g->d_fmap, g->d_merged, g->d_endstate, g->d_llpart, g->d_bdiag, g->d_blkbuf};
+                    g->d_fmap, g->d_merged, g->d_endstate, g->d_llpart, g->d_bdiag, g->d_blkbuf, g->d_ms, g->d_bt, g->d_fconst};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -517,20 +612,21 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
 {
     const int64_t T = g->T, S = g->S;
     if (!g->d_T2) {
-        const double need = (double)S * (double)T * 2.0;
+        const double need = (double)std::max(g->nms, 1) * (double)T * 2.0;
         HS_CHECK(need < 220e9, HMMSORT_ENOMEM,
                  "Viterbi needs %.1f GB of back-pointers; decode in chunks", need / 1e9);
-        int rc = dalloc(&g->d_T2, (size_t)S * T, &g->bytes);
+        int rc = dalloc(&g->d_T2, (size_t)std::max(g->nms, 1) * T, &g->bytes);
         if (rc) return rc;
     }
     BlockArgs a;
     a.y = d_y; a.T = T; a.S = (int)S; a.B = (int)g->B; a.H = (int)g->H;
     a.mean = g->d_mean; a.lp0 = g->d_lp0; a.src0 = g->d_src0; a.tinfo = g->d_tinfo;
     a.tsrc = g->d_tsrc; a.tlp = g->d_tlp; a.ntail = g->ntail;
+    a.ms = (const MsRec *)g->d_ms; a.nms = g->nms;
     a.c0 = -kLog2Pi - g->lsig;
     a.den = 2.0 * (g->sigma * g->sigma);
     a.rden = 1.0 / a.den;
-    a.T2 = g->d_T2; a.endv = g->d_endv; a.warmv = g->d_warmv;
+    a.T2c = g->d_T2; a.endv = g->d_endv; a.warmv = g->d_warmv;
     a.gbuf = g->blk_cols_lds ? nullptr : g->d_blkbuf;
     size_t lds = (g->blk_cols_lds ? 2 * S * 8 : 0) + (g->blk_tail_lds ? (size_t)g->ntail * 12 + 8 : 0);
     int threads = (int)std::min<int64_t>(1024, (S + 63) / 64 * 64);
@@ -552,19 +648,29 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
                            g->d_bdiag);
         HS_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_block_map, dim3(nb), dim3(256), (size_t)S * sizeof(int16_t), st, g->d_T2, T,
-                       (int)S, (int)g->B, g->d_fmap, g->d_merged, d_x);
+    // backtrace: rows of T2c staged W at a time; bt in LDS when it fits
+    const int nms1 = std::max(g->nms, 1);
+    int W = (int)std::max<int64_t>(1, std::min<int64_t>(64, (32 * 1024) / (nms1 * 2)));
+    size_t lds_map = (size_t)((S + 3) & ~3) * 2 + (size_t)((W * g->nms + 3) & ~3) * 2;
+    const int bt_lds = lds_map + (size_t)S * 4 <= 150 * 1024;
+    if (bt_lds) lds_map += (size_t)S * 4;
+    if (lds_map > 64 * 1024)
+        HS_HIP(hipFuncSetAttribute((const void *)k_block_map,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_map));
+    hipLaunchKernelGGL(k_block_map, dim3(nb), dim3(256), lds_map, st, g->d_T2, g->d_bt, g->nms, W,
+                       bt_lds, T, (int)S, (int)g->B, g->d_fmap, g->d_fconst, g->d_merged, d_x);
     HS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_block_compose, dim3(1), dim3(64), 0, st, g->d_endv, g->d_fmap, (int)S, nb,
-                       g->d_endstate);
+    hipLaunchKernelGGL(k_block_compose, dim3(1), dim3(256), 0, st, g->d_endv, g->d_fmap, g->d_fconst,
+                       (int)S, nb, g->d_endstate);
     HS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_block_finish, dim3((nb + 63) / 64), dim3(64), 0, st, g->d_T2, T, (int)S,
-                       (int)g->B, nb, g->d_endstate, g->d_merged, d_x);
+    hipLaunchKernelGGL(k_block_finish, dim3((nb + 63) / 64), dim3(64), 0, st, g->d_T2, g->d_bt, g->nms,
+                       T, (int)S, (int)g->B, nb, g->d_endstate, g->d_merged, d_x);
     HS_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_block_ll, dim3(nb), dim3(256), 0, st, d_y, d_x, T, (int)S, (int)g->B,
                        g->d_mean, g->d_in_ptr, g->d_in_src, g->d_in_lp, a.c0, a.den, g->d_llpart);
     HS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_block_ll_sum, dim3(1), dim3(64), 0, st, g->d_llpart, nb, d_ll);
+    const size_t lds_ll = (size_t)nb * 24 <= 60 * 1024 ? (size_t)nb * 24 : 0;
+    hipLaunchKernelGGL(k_block_ll_sum, dim3(1), dim3(256), lds_ll, st, g->d_llpart, nb, d_ll);
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }

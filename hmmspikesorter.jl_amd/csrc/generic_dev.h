@@ -23,8 +23,10 @@ struct GenericDev {
     int ntail = -1;
     double *d_lp0 = nullptr, *d_tlp = nullptr, *d_endv = nullptr, *d_warmv = nullptr;
     double *d_llpart = nullptr, *d_blkbuf = nullptr;
-    int32_t *d_src0 = nullptr, *d_tinfo = nullptr, *d_tsrc = nullptr;
-    int16_t *d_fmap = nullptr, *d_endstate = nullptr;
+    int32_t *d_src0 = nullptr, *d_tinfo = nullptr, *d_tsrc = nullptr, *d_bt = nullptr;
+    void *d_ms = nullptr;  // MsRec[nms]
+    int nms = 0;
+    int16_t *d_fmap = nullptr, *d_endstate = nullptr, *d_fconst = nullptr;
     int64_t *d_merged = nullptr;
     unsigned long long *d_bdiag = nullptr;
     int64_t upd_bytes = 0;

@@ -13,6 +13,9 @@ temps = np.asfortranarray(np.stack([H.create_spike_template(K, 3.0 + 0.3 * i, 0.
 sm = H.StateMatrix.create(N, K, np.log(pp), True)
 y = H.create_signal(T, 0.3, pp, temps, seed=8)
 H.set_option("engine", H.ENGINE_BLOCKED)
+import os
+H.set_option("block", int(os.environ.get("HMMSORT_BLOCK", "0")))
+H.set_option("halo", int(os.environ.get("HMMSORT_HALO", "0")))
 p = device.Plan(T, sm, temps, 0.3)
 print("plan", p.info(), flush=True)
 dy = torch.from_numpy(y).cuda()
