@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhmmsort_hip.so")
+LIB_PATH = os.environ.get("HMMSORT_LIB", os.path.join(_HERE, "libhmmsort_hip.so"))  # override: A/B builds
 
 # Julia Tuple{Int64,Int64,Float64} == struct hmm_trans (include/hmmsort.h)
 TRANS_DTYPE = np.dtype([("src", np.int64), ("dst", np.int64), ("lp", np.float64)], align=True)

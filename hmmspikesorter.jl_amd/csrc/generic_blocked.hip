@@ -131,8 +131,8 @@ __global__ __launch_bounds__(1024) void gen_vit_block(BlockArgs a)
     int ms_j = 0, ms_s0 = 0, ms_ti = 0;  // this thread's multi-source state (phase B)
     double ms_l0 = 0.0, ms_mean = 0.0;
     if (CACHE && tid < a.nms) {
-        const MsRec r = a.ms[tid];
-        ms_j = r.j; ms_s0 = r.s0; ms_ti = r.ti; ms_l0 = r.lp0; ms_mean = r.mean;
+        ms_j = a.ms[tid].j;
+        ms_s0 = a.src0[ms_j]; ms_ti = a.tinfo[ms_j]; ms_l0 = a.lp0[ms_j]; ms_mean = a.mean[ms_j];
     }
     int par = 0;  // cur = column par, prev = column par ^ 1
     {   // first column: viterbi.jl:55-63 at the start of the signal, flat (emissions) elsewhere
@@ -169,19 +169,17 @@ __global__ __launch_bounds__(1024) void gen_vit_block(BlockArgs a)
                 }
             }
             for (int m = tid; m < a.nms; m += nt) {
-                MsRec r;
-                if (m != tid) r = a.ms[m];
-                const int j = (m == tid) ? ms_j : r.j;
-                const int s0 = (m == tid) ? ms_s0 : r.s0;
-                const double l0 = (m == tid) ? ms_l0 : r.lp0;
+                const int j = (m == tid) ? ms_j : a.ms[m].j;
+                const int s0 = (m == tid) ? ms_s0 : a.src0[j];
+                const double l0 = (m == tid) ? ms_l0 : a.lp0[j];
                 const double tt = prev[s0] + l0;
                 const bool up = tt > -INFINITY;
                 double best = up ? tt : -INFINITY;
                 int arg = up ? s0 + 1 : 1;
-                const int ti = (m == tid) ? ms_ti : r.ti;
+                const int ti = (m == tid) ? ms_ti : a.tinfo[j];
                 if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg);
                 else block_tail(prev, ti, a.tsrc, a.tlp, best, arg);
-                const double v = best + funcl_m(yt, (m == tid) ? ms_mean : r.mean, c0, den, rden);
+                const double v = best + funcl_m(yt, (m == tid) ? ms_mean : a.mean[j], c0, den, rden);
                 cur[j] = v;
                 if (own) psi[m] = (int16_t)arg;
                 if (at_warm) warm[j] = v;
