@@ -98,14 +98,18 @@ __device__ __forceinline__ void block_tail(PrevPtr prev, int ti, SrcPtr tsrc, Lp
 // registers (S <= 4096); SPT = 0 re-reads them each sample (coalesced, L2-resident).  GCOL: the
 // two trellis columns live in global memory (S too large for LDS); TLDS: tails staged in LDS.
 // Address spaces are fixed at compile time so that column accesses are ds_* (not flat) operations.
+// Two workgroups of 16 waves per CU need 8 waves per SIMD, i.e. at most 64 VGPRs: pinned, because a
+// 65th register silently halves the occupancy (measured: 11.8 -> 16.4 ms at 4 M samples).
 template <int SPT, bool GCOL, bool TLDS>
-__global__ __launch_bounds__(1024) void gen_vit_block(BlockArgs a)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void gen_vit_block(BlockArgs a)
 {
     extern __shared__ double sh[];
     constexpr bool CACHE = SPT > 0;
     constexpr int NS = CACHE ? SPT : 1;
     const int c = blockIdx.x, S = a.S, tid = threadIdx.x, nt = blockDim.x;
-    double *l_tlp = sh + (GCOL ? 0 : 2 * S);
+    const int CS = S + 1;  // LDS column stride: entry S of a column is a write-only dummy slot
+    double *l_tlp = sh + (GCOL ? 0 : 2 * CS);
     int32_t *l_tsrc = (int32_t *)(l_tlp + a.ntail);
     if (TLDS)
         for (int i = tid; i < a.ntail; i += nt) { l_tlp[i] = a.tlp[i]; l_tsrc[i] = a.tsrc[i]; }
@@ -117,15 +121,15 @@ __global__ __launch_bounds__(1024) void gen_vit_block(BlockArgs a)
     double *gcol = GCOL ? a.gbuf + (int64_t)c * 2 * S : nullptr;
 
     double mean_r[NS], lp0_r[NS];
-    int src0_r[NS], ti_r[NS];
+    unsigned sw_r[NS];  // source | store index << 16 (store index S = the dummy slot; S < 2^15)
     if (CACHE) {
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             const int j = tid + i * nt < S ? tid + i * nt : S - 1;
             mean_r[i] = a.mean[j];
             lp0_r[i] = a.lp0[j];
-            src0_r[i] = a.src0[j];
-            ti_r[i] = a.tinfo[j];
+            const int wj = (tid + i * nt < S && (a.tinfo[j] & 255) == 0) ? j : S;
+            sw_r[i] = (unsigned)a.src0[j] | ((unsigned)wj << 16);
         }
     }
     int ms_j = 0, ms_s0 = 0, ms_ti = 0;  // this thread's multi-source state (phase B)
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(1024) void gen_vit_block(BlockArgs a)
         const double y0 = a.y[w];
         for (int j = tid; j < S; j += nt) {
             const double v = (w == 0 && j == 0) ? 0.0 : funcl_m(y0, a.mean[j], c0, den, rden);
-            if (GCOL) gcol[j] = v; else sh[j] = v;
+            if (GCOL) gcol[j] = v; else sh[j] = v;  // column 0
             if (s > 0 && w == s - 1) warm[j] = v;
         }
     }
@@ -153,20 +157,21 @@ __global__ __launch_bounds__(1024) void gen_vit_block(BlockArgs a)
         const bool own = t >= s, at_warm = t == s - 1;
         int16_t *psi = a.T2c + (int64_t)a.nms * t;
         if (CACHE) {  // columns in LDS
-            const double *prev = sh + (par ^ 1) * S;
-            double *cur = sh + par * S;
-            // phase A: every state's first transition, branch-free; multi-source states (ti != 0)
-            // are finished in phase B by the leading waves, so that the other waves never diverge
+            const double *prev = sh + (par ^ 1) * CS;
+            double *cur = sh + par * CS;
+            // phase A: the first transition of every state, no branches.  A finite value always
+            // beats fill(-Inf) (:80) and a -Inf stays -Inf, so the compare is dropped here; states
+            // with more transitions (stored to the dummy slot here) are finished in phase B by the
+            // leading waves, so that the other waves never diverge.
+            double pv[NS];  // all reads of the previous column before any write of this one
+#pragma unroll
+            for (int i = 0; i < NS; i++) pv[i] = prev[sw_r[i] & 0xffffu];
 #pragma unroll
             for (int i = 0; i < NS; i++) {
-                const int j = tid + i * nt;
-                const double tt = prev[src0_r[i]] + lp0_r[i];  // :79
-                const bool up = tt > -INFINITY;                // :80 against fill(-Inf)
-                const double v = (up ? tt : -INFINITY) + funcl_m(yt, mean_r[i], c0, den, rden);
-                if (j < S && (ti_r[i] & 255) == 0) {
-                    cur[j] = v;                                // :85-87
-                    if (at_warm) warm[j] = v;
-                }
+                const int wj = (int)(sw_r[i] >> 16);
+                const double v = (pv[i] + lp0_r[i]) + funcl_m(yt, mean_r[i], c0, den, rden);  // :79, :85-87
+                cur[wj] = v;
+                if (at_warm && wj < S) warm[wj] = v;
             }
             for (int m = tid; m < a.nms; m += nt) {
                 const int j = (m == tid) ? ms_j : a.ms[m].j;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(1024) void gen_vit_block(BlockArgs a)
             }
         } else {
             // same two phases with the constants re-read every sample
-            const double *prevl = sh + (par ^ 1) * S;
+            const double *prevl = sh + (par ^ 1) * CS;
             const double *prevg = GCOL ? gcol + (par ^ 1) * S : nullptr;
 #pragma unroll 2
             for (int j = tid; j < S; j += nt) {
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(1024) void gen_vit_block(BlockArgs a)
                 const double tt = (GCOL ? prevg[s0] : prevl[s0]) + l0;
                 const double v = (tt > -INFINITY ? tt : -INFINITY) + q;
                 if ((ti & 255) == 0) {
-                    if (GCOL) gcol[par * S + j] = v; else sh[par * S + j] = v;
+                    if (GCOL) gcol[par * S + j] = v; else sh[par * CS + j] = v;
                     if (at_warm) warm[j] = v;
                 }
             }
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(1024) void gen_vit_block(BlockArgs a)
                     else block_tail(prevl, ti, a.tsrc, a.tlp, best, arg);
                 }
                 const double v = best + q;
-                if (GCOL) gcol[par * S + j] = v; else sh[par * S + j] = v;
+                if (GCOL) gcol[par * S + j] = v; else sh[par * CS + j] = v;
                 if (own) psi[m] = (int16_t)arg;
                 if (at_warm) warm[j] = v;
             }
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(1024) void gen_vit_block(BlockArgs a)
     }
     __syncthreads();
     for (int j = tid; j < S; j += nt)
-        a.endv[(int64_t)c * S + j] = GCOL ? gcol[par * S + j] : sh[par * S + j];
+        a.endv[(int64_t)c * S + j] = GCOL ? gcol[par * S + j] : sh[par * CS + j];
 }
 
 // Boundary certificate: spread over the states of (warm column of block c) - (end column of block
@@ -574,8 +579,8 @@ int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t
     const size_t S = (size_t)g->S, nb = (size_t)g->nblk;
     // LDS: two columns + the multi-source tails, else columns in a per-block global scratch
     const size_t tail_b = (size_t)g->ntail * 12 + 8;
-    g->blk_cols_lds = 2 * S * 8 <= 150 * 1024;
-    g->blk_tail_lds = (g->blk_cols_lds ? 2 * S * 8 : 0) + tail_b <= 150 * 1024;
+    g->blk_cols_lds = 2 * (S + 1) * 8 <= 150 * 1024;
+    g->blk_tail_lds = (g->blk_cols_lds ? 2 * (S + 1) * 8 : 0) + tail_b <= 150 * 1024;
     if ((rc = dalloc(&g->d_endv, nb * S, &g->bytes)) || (rc = dalloc(&g->d_warmv, nb * S, &g->bytes)) ||
         (rc = dalloc(&g->d_fmap, nb * S, &g->bytes)) || (rc = dalloc(&g->d_merged, nb, &g->bytes)) ||
         (rc = dalloc(&g->d_endstate, nb, &g->bytes)) || (rc = dalloc(&g->d_fconst, nb, &g->bytes)) || (rc = dalloc(&g->d_llpart, 3 * nb, &g->bytes)) ||
@@ -626,7 +631,7 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     a.rden = 1.0 / a.den;
     a.T2c = g->d_T2; a.endv = g->d_endv; a.warmv = g->d_warmv;
     a.gbuf = g->blk_cols_lds ? nullptr : g->d_blkbuf;
-    size_t lds = (g->blk_cols_lds ? 2 * S * 8 : 0) + (g->blk_tail_lds ? (size_t)g->ntail * 12 + 8 : 0);
+    size_t lds = (g->blk_cols_lds ? 2 * (S + 1) * 8 : 0) + (g->blk_tail_lds ? (size_t)g->ntail * 12 + 8 : 0);
     int threads = (int)std::min<int64_t>(1024, (S + 63) / 64 * 64);
     const int spt = (int)((S + threads - 1) / threads);
     HS_HIP(hipMemsetAsync(g->d_bdiag, 0, 8 * sizeof(unsigned long long), st));
