@@ -55,6 +55,7 @@ struct BlockArgs {
     int ntail;
     const MsRec *ms;      // [nms] states with more than one incoming transition
     int nms;
+    int nbthr;            // register-cached sweep: leading threads that only do phase B
     double c0, den, rden;  // rden = RN(1/den)
     int16_t *T2c;         // [T][nms]
     double *endv, *warmv; // [nblk][S]
@@ -100,7 +101,7 @@ __device__ __forceinline__ void block_tail(PrevPtr prev, int ti, SrcPtr tsrc, Lp
 // Address spaces are fixed at compile time so that column accesses are ds_* (not flat) operations.
 // Two workgroups of 16 waves per CU need 8 waves per SIMD, i.e. at most 64 VGPRs: pinned, because a
 // 65th register silently halves the occupancy (measured: 11.8 -> 16.4 ms at 4 M samples).
-template <int SPT, bool GCOL, bool TLDS>
+template <int SPT, bool SPEC, bool GCOL, bool TLDS>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void gen_vit_block(BlockArgs a)
 {
@@ -120,23 +121,52 @@ void gen_vit_block(BlockArgs a)
     double *warm = a.warmv + (int64_t)c * S;
     double *gcol = GCOL ? a.gbuf + (int64_t)c * 2 * S : nullptr;
 
-    double mean_r[NS], lp0_r[NS];
-    unsigned sw_r[NS];  // source | store index << 16 (store index S = the dummy slot; S < 2^15)
-    if (CACHE) {
+    // Register-cached sweep.  SPEC (small models, measured faster up to ~2 states per lane): wave-
+    // specialised, the first nbthr threads (whole waves) own the states with several incoming
+    // transitions (phase B, a chain of dependent LDS reads), the others the first transition of
+    // every state (phase A); both run concurrently between two barriers.  Otherwise every thread
+    // does phase A and the leading threads then add phase B.
+    const int nbt = (CACHE && SPEC) ? a.nbthr : 0;
+    const bool is_b = tid < nbt;
+    const int ta = tid - nbt, na = nt - nbt;
+    // The two roles never coexist in a wave, so they share one set of registers:
+    //   phase A: cd[i] = mean, cd[ND+i] = lp of the first transition, ci[i] = source | store << 16
+    //            (store index S = the dummy slot; S < 2^15)
+    //   phase B: cd[0] = mean, cd[1..3] = lp of the first three transitions (-Inf when absent),
+    //            ci[0] = source0 | state << 16, ci[1] = source1 | source2 << 16, ci[2] = the rest
+    constexpr int ND = NS > 2 ? NS : 2, NI = NS > 3 ? NS : 3;
+    double cd[2 * ND];
+    unsigned ci[NI];
+    if (CACHE && !is_b) {
 #pragma unroll
         for (int i = 0; i < NS; i++) {
-            const int j = tid + i * nt < S ? tid + i * nt : S - 1;
-            mean_r[i] = a.mean[j];
-            lp0_r[i] = a.lp0[j];
-            const int wj = (tid + i * nt < S && (a.tinfo[j] & 255) == 0) ? j : S;
-            sw_r[i] = (unsigned)a.src0[j] | ((unsigned)wj << 16);
+            const int jj = ta + i * na;
+            const int j = jj < S ? jj : S - 1;
+            cd[i] = a.mean[j];
+            cd[ND + i] = a.lp0[j];
+            const int wj = (jj < S && (a.tinfo[j] & 255) == 0) ? j : S;
+            ci[i] = (unsigned)a.src0[j] | ((unsigned)wj << 16);
         }
     }
-    int ms_j = 0, ms_s0 = 0, ms_ti = 0;  // this thread's multi-source state (phase B)
-    double ms_l0 = 0.0, ms_mean = 0.0;
-    if (CACHE && tid < a.nms) {
-        ms_j = a.ms[tid].j;
-        ms_s0 = a.src0[ms_j]; ms_ti = a.tinfo[ms_j]; ms_l0 = a.lp0[ms_j]; ms_mean = a.mean[ms_j];
+    int bj = 0, bs0 = 0, bti = 0;  // !SPEC: this thread's multi-source state
+    double bl0 = 0.0, bmean = 0.0;
+    if (CACHE && !SPEC && tid < a.nms) {
+        bj = a.ms[tid].j;
+        bs0 = a.src0[bj]; bti = a.tinfo[bj]; bl0 = a.lp0[bj]; bmean = a.mean[bj];
+    }
+    if (CACHE && is_b) {
+        cd[0] = 0.0; cd[1] = cd[2] = cd[3] = -INFINITY;
+        ci[0] = (unsigned)S << 16; ci[1] = 0; ci[2] = 0;
+        if (tid < a.nms) {
+            const int j = a.ms[tid].j, ti = a.tinfo[j];
+            const int tn = ti & 255, tp = ti >> 8;
+            cd[0] = a.mean[j];
+            cd[1] = a.lp0[j];
+            ci[0] = (unsigned)a.src0[j] | ((unsigned)j << 16);
+            if (tn >= 1) { ci[1] = (unsigned)a.tsrc[tp]; cd[2] = a.tlp[tp]; }
+            if (tn >= 2) { ci[1] |= (unsigned)a.tsrc[tp + 1] << 16; cd[3] = a.tlp[tp + 1]; }
+            ci[2] = (unsigned)(((tp + 2) << 8) | (tn > 2 ? tn - 2 : 0));  // left for the loop
+        }
     }
     int par = 0;  // cur = column par, prev = column par ^ 1
     {   // first column: viterbi.jl:55-63 at the start of the signal, flat (emissions) elsewhere
@@ -159,35 +189,70 @@ void gen_vit_block(BlockArgs a)
         if (CACHE) {  // columns in LDS
             const double *prev = sh + (par ^ 1) * CS;
             double *cur = sh + par * CS;
-            // phase A: the first transition of every state, no branches.  A finite value always
-            // beats fill(-Inf) (:80) and a -Inf stays -Inf, so the compare is dropped here; states
-            // with more transitions (stored to the dummy slot here) are finished in phase B by the
-            // leading waves, so that the other waves never diverge.
-            double pv[NS];  // all reads of the previous column before any write of this one
+            if (!is_b) {  // always true without SPEC
+                // phase A: the first transition of every state, no branches.  A finite value always
+                // beats fill(-Inf) (:80) and a -Inf stays -Inf, so the compare is dropped; states with
+                // more transitions go to the dummy slot here and are computed by the phase-B waves.
+                double pv[NS];  // all reads of the previous column before any write of this one
 #pragma unroll
-            for (int i = 0; i < NS; i++) pv[i] = prev[sw_r[i] & 0xffffu];
+                for (int i = 0; i < NS; i++) pv[i] = prev[ci[i] & 0xffffu];
 #pragma unroll
-            for (int i = 0; i < NS; i++) {
-                const int wj = (int)(sw_r[i] >> 16);
-                const double v = (pv[i] + lp0_r[i]) + funcl_m(yt, mean_r[i], c0, den, rden);  // :79, :85-87
-                cur[wj] = v;
-                if (at_warm && wj < S) warm[wj] = v;
+                for (int i = 0; i < NS; i++) {
+                    const int wj = (int)(ci[i] >> 16);
+                    const double v = (pv[i] + cd[ND + i]) + funcl_m(yt, cd[i], c0, den, rden);  // :79, :85-87
+                    cur[wj] = v;
+                    if (at_warm && wj < S) warm[wj] = v;
+                }
             }
-            for (int m = tid; m < a.nms; m += nt) {
-                const int j = (m == tid) ? ms_j : a.ms[m].j;
-                const int s0 = (m == tid) ? ms_s0 : a.src0[j];
-                const double l0 = (m == tid) ? ms_l0 : a.lp0[j];
-                const double tt = prev[s0] + l0;
-                const bool up = tt > -INFINITY;
-                double best = up ? tt : -INFINITY;
-                int arg = up ? s0 + 1 : 1;
-                const int ti = (m == tid) ? ms_ti : a.tinfo[j];
-                if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg);
-                else block_tail(prev, ti, a.tsrc, a.tlp, best, arg);
-                const double v = best + funcl_m(yt, (m == tid) ? ms_mean : a.mean[j], c0, den, rden);
-                cur[j] = v;
-                if (own) psi[m] = (int16_t)arg;
-                if (at_warm) warm[j] = v;
+            if (!SPEC) {
+                for (int m = tid; m < a.nms; m += nt) {
+                    const int j = (m == tid) ? bj : a.ms[m].j;
+                    const int s0 = (m == tid) ? bs0 : a.src0[j];
+                    const double tt = prev[s0] + ((m == tid) ? bl0 : a.lp0[j]);
+                    const bool up = tt > -INFINITY;
+                    double best = up ? tt : -INFINITY;
+                    int arg = up ? s0 + 1 : 1;
+                    const int ti = (m == tid) ? bti : a.tinfo[j];
+                    if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg);
+                    else block_tail(prev, ti, a.tsrc, a.tlp, best, arg);
+                    const double v = best + funcl_m(yt, (m == tid) ? bmean : a.mean[j], c0, den, rden);
+                    cur[j] = v;
+                    if (own) psi[m] = (int16_t)arg;
+                    if (at_warm) warm[j] = v;
+                }
+            } else if (is_b) {
+                // phase B: list order, strict '>' (:76-84); absent transitions carry lp = -Inf
+                if (tid < a.nms) {
+                    const int s0 = (int)(ci[0] & 0xffffu), j = (int)(ci[0] >> 16);
+                    const int s1 = (int)(ci[1] & 0xffffu), s2 = (int)(ci[1] >> 16);
+                    const double t0 = prev[s0] + cd[1], t1 = prev[s1] + cd[2], t2 = prev[s2] + cd[3];
+                    double best = -INFINITY;
+                    int arg = 1;
+                    if (t0 > best) { best = t0; arg = s0 + 1; }
+                    if (t1 > best) { best = t1; arg = s1 + 1; }
+                    if (t2 > best) { best = t2; arg = s2 + 1; }
+                    if (ci[2] & 255u) {
+                        if (TLDS) block_tail(prev, (int)ci[2], l_tsrc, l_tlp, best, arg);
+                        else block_tail(prev, (int)ci[2], a.tsrc, a.tlp, best, arg);
+                    }
+                    const double v = best + funcl_m(yt, cd[0], c0, den, rden);
+                    cur[j] = v;
+                    if (own) psi[tid] = (int16_t)arg;
+                    if (at_warm) warm[j] = v;
+                }
+                for (int m = tid + nbt; m < a.nms; m += nbt) {  // more such states than threads
+                    const int j = a.ms[m].j, s0 = a.src0[j], ti = a.tinfo[j];
+                    const double tt = prev[s0] + a.lp0[j];
+                    const bool up = tt > -INFINITY;
+                    double best = up ? tt : -INFINITY;
+                    int arg = up ? s0 + 1 : 1;
+                    if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg);
+                    else block_tail(prev, ti, a.tsrc, a.tlp, best, arg);
+                    const double v = best + funcl_m(yt, a.mean[j], c0, den, rden);
+                    cur[j] = v;
+                    if (own) psi[m] = (int16_t)arg;
+                    if (at_warm) warm[j] = v;
+                }
             }
         } else {
             // same two phases with the constants re-read every sample
@@ -599,14 +664,14 @@ void blocked_destroy(GenericDev *g)
         if (p) (void)hipFree(p);
 }
 
-template <int SPT, bool GCOL, bool TLDS>
+template <int SPT, bool SPEC, bool GCOL, bool TLDS>
 static int launch_block_sweep(GenericDev *g, const BlockArgs &a, int threads, size_t lds,
                               hipStream_t st)
 {
     if (lds > 64 * 1024)
-        HS_HIP(hipFuncSetAttribute((const void *)gen_vit_block<SPT, GCOL, TLDS>,
+        HS_HIP(hipFuncSetAttribute((const void *)gen_vit_block<SPT, SPEC, GCOL, TLDS>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((gen_vit_block<SPT, GCOL, TLDS>), dim3((unsigned)g->nblk), dim3(threads), lds, st, a);
+    hipLaunchKernelGGL((gen_vit_block<SPT, SPEC, GCOL, TLDS>), dim3((unsigned)g->nblk), dim3(threads), lds, st, a);
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }
@@ -632,18 +697,30 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     a.T2c = g->d_T2; a.endv = g->d_endv; a.warmv = g->d_warmv;
     a.gbuf = g->blk_cols_lds ? nullptr : g->d_blkbuf;
     size_t lds = (g->blk_cols_lds ? 2 * (S + 1) * 8 : 0) + (g->blk_tail_lds ? (size_t)g->ntail * 12 + 8 : 0);
-    int threads = (int)std::min<int64_t>(1024, (S + 63) / 64 * 64);
-    const int spt = (int)((S + threads - 1) / threads);
+    // register-cached sweep: wave-specialised (nbthr phase-B threads + phase-A threads with <= 2
+    // states each) when that fits 1024 threads, else every thread takes spt <= 4 states
+    int threads = (int)std::min<int64_t>(1024, (S + 63) / 64 * 64), spt = 0, nbthr = 0;
+    if (g->blk_cols_lds && g->blk_tail_lds) {
+        const int nbw = std::min((g->nms + 63) / 64 * 64, 512);
+        for (int k = 1; k <= 2 && !spt && g->nms > 0; k++) {
+            const int na = (int)(((S + k - 1) / k + 63) / 64 * 64);
+            if (nbw + na <= 1024) { spt = k; threads = nbw + na; nbthr = nbw; }
+        }
+        if (!spt && S <= 4096) spt = (int)((S + threads - 1) / threads) <= 2 ? (int)((S + threads - 1) / threads) : 4;
+    }
+    a.nbthr = nbthr;
     HS_HIP(hipMemsetAsync(g->d_bdiag, 0, 8 * sizeof(unsigned long long), st));
     int rc;
     const bool gcol = !g->blk_cols_lds, tl = g->blk_tail_lds;
-    if (!gcol && tl && spt <= 1) rc = launch_block_sweep<1, false, true>(g, a, threads, lds, st);
-    else if (!gcol && tl && spt <= 2) rc = launch_block_sweep<2, false, true>(g, a, threads, lds, st);
-    else if (!gcol && tl && spt <= 4) rc = launch_block_sweep<4, false, true>(g, a, threads, lds, st);
-    else if (!gcol && tl) rc = launch_block_sweep<0, false, true>(g, a, threads, lds, st);
-    else if (!gcol) rc = launch_block_sweep<0, false, false>(g, a, threads, lds, st);
-    else if (tl) rc = launch_block_sweep<0, true, true>(g, a, threads, lds, st);
-    else rc = launch_block_sweep<0, true, false>(g, a, threads, lds, st);
+    if (spt == 1 && nbthr) rc = launch_block_sweep<1, true, false, true>(g, a, threads, lds, st);
+    else if (spt == 2 && nbthr) rc = launch_block_sweep<2, true, false, true>(g, a, threads, lds, st);
+    else if (spt == 1) rc = launch_block_sweep<1, false, false, true>(g, a, threads, lds, st);
+    else if (spt == 2) rc = launch_block_sweep<2, false, false, true>(g, a, threads, lds, st);
+    else if (spt == 4) rc = launch_block_sweep<4, false, false, true>(g, a, threads, lds, st);
+    else if (!gcol && tl) rc = launch_block_sweep<0, false, false, true>(g, a, threads, lds, st);
+    else if (!gcol) rc = launch_block_sweep<0, false, false, false>(g, a, threads, lds, st);
+    else if (tl) rc = launch_block_sweep<0, false, true, true>(g, a, threads, lds, st);
+    else rc = launch_block_sweep<0, false, true, false>(g, a, threads, lds, st);
     if (rc) return rc;
     const int nb = (int)g->nblk;
     if (nb > 1) {
