@@ -286,6 +286,31 @@ def main():
         return nchan * T / per / 1e6
     mc = multi_channel(args.channels) if (args.channels > 1 and not args.time_sharded) else None
 
+    # ---- overlap-resolving decode: the reference's own Viterbi-test model,
+    # test/runtests.jl:17-34 -- 2 templates, K=60, allow_overlaps=true, 3600 states -- through the
+    # blocked engine, device-resident (untimed extra, rank 0 of a 1-GPU run only) ----
+    def overlap_decode(To=2_000_000):
+        t2 = np.asfortranarray(temps[:, :2])
+        ppo = [0.003, 0.001]
+        smo = H.StateMatrix.create(2, K, np.log(ppo), True)
+        yo = torch.from_numpy(H.create_signal(To, sigma, ppo, t2, seed=seed + 7)).to(dev)
+        xo = torch.zeros(To, dtype=torch.int16, device=dev)
+        po = H.Plan(To, smo, t2, sigma)
+        io = po.info()
+        po.viterbi(yo, xo, dll, stream); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            po.viterbi(yo, xo, dll, stream)
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t) / 3
+        d = po.diagnostics(stream)
+        po.close()
+        return {"model": "N=2 K=%d allow_overlaps=true, %d states" % (K, smo.nstates), "samples": To,
+                "engine": {1: "strict", 2: "ring", 3: "blocked"}.get(io["engine"], io["engine"]),
+                "block": io["block"], "halo": io["halo"], "Msamples_s": To / per / 1e6,
+                "boundary_check_fails": d[0], "max_boundary_spread": d[2]}
+    ov = overlap_decode() if (rank == 0 and world == 1 and K >= 17) else None
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         res = {
@@ -320,6 +345,7 @@ def main():
                        "sum_kernel_ms_per_step": step_ms_kernels,
                        "em_iteration_ms": em_ms, "em_sigma_after_10": em_sigma,
                        "multi_channel": {"channels_per_gpu": args.channels, "Msamples_s": mc} if mc else None,
+                       "overlap_decode": ov,
                        "diag": diag[:7], "workspace_GB": info["workspace_bytes"] / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline:
