@@ -174,7 +174,6 @@ void gen_vit_block(BlockArgs a)
         for (int j = tid; j < S; j += nt) {
             const double v = (w == 0 && j == 0) ? 0.0 : funcl_m(y0, a.mean[j], c0, den, rden);
             if (GCOL) gcol[j] = v; else sh[j] = v;  // column 0
-            if (s > 0 && w == s - 1) warm[j] = v;
         }
     }
     double ynext = a.y[w + 1 < e ? w + 1 : w];
@@ -184,7 +183,10 @@ void gen_vit_block(BlockArgs a)
         if (GCOL) { __threadfence_block(); __syncthreads(); }
         else lds_barrier();
         par ^= 1;
-        const bool own = t >= s, at_warm = t == s - 1;
+        if (t == s && s > 0)  // the column of sample s-1 is what the boundary certificate compares
+            for (int j = tid; j < S; j += nt)
+                warm[j] = GCOL ? gcol[(par ^ 1) * S + j] : sh[(par ^ 1) * CS + j];
+        const bool own = t >= s;
         int16_t *psi = a.T2c + (int64_t)a.nms * t;
         if (CACHE) {  // columns in LDS
             const double *prev = sh + (par ^ 1) * CS;
@@ -201,7 +203,6 @@ void gen_vit_block(BlockArgs a)
                     const int wj = (int)(ci[i] >> 16);
                     const double v = (pv[i] + cd[ND + i]) + funcl_m(yt, cd[i], c0, den, rden);  // :79, :85-87
                     cur[wj] = v;
-                    if (at_warm && wj < S) warm[wj] = v;
                 }
             }
             if (!SPEC) {
@@ -218,7 +219,6 @@ void gen_vit_block(BlockArgs a)
                     const double v = best + funcl_m(yt, (m == tid) ? bmean : a.mean[j], c0, den, rden);
                     cur[j] = v;
                     if (own) psi[m] = (int16_t)arg;
-                    if (at_warm) warm[j] = v;
                 }
             } else if (is_b) {
                 // phase B: list order, strict '>' (:76-84); absent transitions carry lp = -Inf
@@ -238,7 +238,6 @@ void gen_vit_block(BlockArgs a)
                     const double v = best + funcl_m(yt, cd[0], c0, den, rden);
                     cur[j] = v;
                     if (own) psi[tid] = (int16_t)arg;
-                    if (at_warm) warm[j] = v;
                 }
                 for (int m = tid + nbt; m < a.nms; m += nbt) {  // more such states than threads
                     const int j = a.ms[m].j, s0 = a.src0[j], ti = a.tinfo[j];
@@ -251,7 +250,6 @@ void gen_vit_block(BlockArgs a)
                     const double v = best + funcl_m(yt, a.mean[j], c0, den, rden);
                     cur[j] = v;
                     if (own) psi[m] = (int16_t)arg;
-                    if (at_warm) warm[j] = v;
                 }
             }
         } else {
@@ -266,7 +264,6 @@ void gen_vit_block(BlockArgs a)
                 const double v = (tt > -INFINITY ? tt : -INFINITY) + q;
                 if ((ti & 255) == 0) {
                     if (GCOL) gcol[par * S + j] = v; else sh[par * CS + j] = v;
-                    if (at_warm) warm[j] = v;
                 }
             }
             for (int m = tid; m < a.nms; m += nt) {
@@ -287,13 +284,89 @@ void gen_vit_block(BlockArgs a)
                 const double v = best + q;
                 if (GCOL) gcol[par * S + j] = v; else sh[par * CS + j] = v;
                 if (own) psi[m] = (int16_t)arg;
-                if (at_warm) warm[j] = v;
             }
         }
     }
     __syncthreads();
     for (int j = tid; j < S; j += nt)
         a.endv[(int64_t)c * S + j] = GCOL ? gcol[par * S + j] : sh[par * CS + j];
+}
+
+// Models of 4 097 .. 12 288 states (N=3, K=60 has 10 621): ONE column in LDS, updated in place.  Every thread first reads all the sources it needs into
+// registers, a barrier, then writes its states.  One workgroup per CU, 128 VGPRs.
+template <int SPT>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void gen_vit_block1(BlockArgs a)
+{
+    extern __shared__ double sh[];  // column [S] + dummy slot, then the tails
+    const int c = blockIdx.x, S = a.S, tid = threadIdx.x, nt = blockDim.x;
+    double *col = sh;
+    double *l_tlp = sh + (S + 1);
+    int32_t *l_tsrc = (int32_t *)(l_tlp + a.ntail);
+    for (int i = tid; i < a.ntail; i += nt) { l_tlp[i] = a.tlp[i]; l_tsrc[i] = a.tsrc[i]; }
+    const int64_t s = (int64_t)c * a.B;
+    const int64_t e = (s + a.B < a.T) ? s + a.B : a.T;
+    const int64_t w = (s - a.H > 0) ? s - a.H : 0;
+    const double c0 = a.c0, den = a.den, rden = a.rden;
+    double *warm = a.warmv + (int64_t)c * S;
+    double cd[2 * SPT];   // mean, lp of the first transition
+    unsigned ci[SPT];     // source | store index << 16 (S = dummy: multi-source or past the end)
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+        const int jj = tid + i * nt;
+        const int j = jj < S ? jj : S - 1;
+        cd[i] = a.mean[j];
+        cd[SPT + i] = a.lp0[j];
+        const int wj = (jj < S && (a.tinfo[j] & 255) == 0) ? j : S;
+        ci[i] = (unsigned)a.src0[j] | ((unsigned)wj << 16);
+    }
+    const bool has_b = tid < a.nms;  // host guarantees nms <= blockDim.x
+    int bj = 0, bs0 = 0, bti = 0;
+    double bl0 = 0.0, bmean = 0.0;
+    if (has_b) {
+        bj = a.ms[tid].j;
+        bs0 = a.src0[bj]; bti = a.tinfo[bj]; bl0 = a.lp0[bj]; bmean = a.mean[bj];
+    }
+    {
+        const double y0 = a.y[w];
+        for (int j = tid; j < S; j += nt) {
+            const double v = (w == 0 && j == 0) ? 0.0 : funcl_m(y0, a.mean[j], c0, den, rden);
+            col[j] = v;
+        }
+    }
+    double ynext = a.y[w + 1 < e ? w + 1 : w];
+    for (int64_t t = w + 1; t < e; t++) {
+        const double yt = ynext;
+        ynext = a.y[t + 1 < e ? t + 1 : t];
+        const bool own = t >= s;
+        lds_barrier();  // the column of sample t-1 is complete
+        if (t == s)     // ... and for t = s it is the warm column the certificate looks at
+            for (int j = tid; j < S; j += nt) warm[j] = col[j];
+        double pv[SPT];
+#pragma unroll
+        for (int i = 0; i < SPT; i++) pv[i] = col[ci[i] & 0xffffu];
+        double best = -INFINITY;
+        int arg = 1;
+        if (has_b) {
+            const double tt = col[bs0] + bl0;
+            if (tt > best) { best = tt; arg = bs0 + 1; }
+            block_tail(col, bti, l_tsrc, l_tlp, best, arg);
+        }
+        lds_barrier();  // every read of sample t-1 has returned: overwrite in place
+#pragma unroll
+        for (int i = 0; i < SPT; i++) {
+            const int wj = (int)(ci[i] >> 16);
+            const double v = (pv[i] + cd[SPT + i]) + funcl_m(yt, cd[i], c0, den, rden);
+            col[wj] = v;
+        }
+        if (has_b) {
+            const double v = best + funcl_m(yt, bmean, c0, den, rden);
+            col[bj] = v;
+            if (own) a.T2c[(int64_t)a.nms * t + tid] = (int16_t)arg;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < S; j += nt) a.endv[(int64_t)c * S + j] = col[j];
 }
 
 // Boundary certificate: spread over the states of (warm column of block c) - (end column of block
@@ -645,13 +718,19 @@ int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t
     // LDS: two columns + the multi-source tails, else columns in a per-block global scratch
     const size_t tail_b = (size_t)g->ntail * 12 + 8;
     g->blk_cols_lds = 2 * (S + 1) * 8 <= 150 * 1024;
+    // above 4096 states the register-cached two-column kernel no longer fits 64 VGPRs; one column
+    // updated in place with cached constants (1 workgroup per CU) beats re-reading them (measured
+    // 90 vs 36 Msamples/s around 9 500 states)
+    g->blk_onecol = S > 4096 && (S + 1) * 8 + tail_b <= 158 * 1024 && S <= 12 * 1024 &&
+                    g->nms <= 1024;
     g->blk_tail_lds = (g->blk_cols_lds ? 2 * (S + 1) * 8 : 0) + tail_b <= 150 * 1024;
     if ((rc = dalloc(&g->d_endv, nb * S, &g->bytes)) || (rc = dalloc(&g->d_warmv, nb * S, &g->bytes)) ||
         (rc = dalloc(&g->d_fmap, nb * S, &g->bytes)) || (rc = dalloc(&g->d_merged, nb, &g->bytes)) ||
         (rc = dalloc(&g->d_endstate, nb, &g->bytes)) || (rc = dalloc(&g->d_fconst, nb, &g->bytes)) || (rc = dalloc(&g->d_llpart, 3 * nb, &g->bytes)) ||
         (rc = dalloc(&g->d_bdiag, 8, &g->bytes)))
         return rc;
-    if (!g->blk_cols_lds && (rc = dalloc(&g->d_blkbuf, nb * 2 * S, &g->bytes))) return rc;
+    if (!g->blk_cols_lds && !g->blk_onecol && (rc = dalloc(&g->d_blkbuf, nb * 2 * S, &g->bytes)))
+        return rc;
     HS_HIP(hipMemset(g->d_bdiag, 0, 8 * sizeof(unsigned long long)));
     return HMMSORT_OK;
 }
@@ -712,6 +791,22 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     HS_HIP(hipMemsetAsync(g->d_bdiag, 0, 8 * sizeof(unsigned long long), st));
     int rc;
     const bool gcol = !g->blk_cols_lds, tl = g->blk_tail_lds;
+    if (g->blk_onecol) {
+        const size_t lds1 = (size_t)(S + 1) * 8 + (size_t)g->ntail * 12 + 8;
+        const int spt1 = (int)((S + 1023) / 1024);
+        auto go = [&](auto kern) -> int {
+            HS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds1));
+            hipLaunchKernelGGL(kern, dim3((unsigned)g->nblk), dim3(1024), lds1, st, a);
+            HS_HIP(hipGetLastError());
+            return HMMSORT_OK;
+        };
+        if (spt1 <= 6) rc = go(gen_vit_block1<6>);
+        else if (spt1 <= 8) rc = go(gen_vit_block1<8>);
+        else if (spt1 <= 10) rc = go(gen_vit_block1<10>);
+        else if (spt1 <= 11) rc = go(gen_vit_block1<11>);
+        else rc = go(gen_vit_block1<12>);
+    } else
     if (spt == 1 && nbthr) rc = launch_block_sweep<1, true, false, true>(g, a, threads, lds, st);
     else if (spt == 2 && nbthr) rc = launch_block_sweep<2, true, false, true>(g, a, threads, lds, st);
     else if (spt == 1) rc = launch_block_sweep<1, false, false, true>(g, a, threads, lds, st);

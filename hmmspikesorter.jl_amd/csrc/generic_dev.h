@@ -18,7 +18,7 @@ struct GenericDev {
     double *d_gbuf = nullptr; // 3*S state-vector scratch when LDS is too small
     bool use_global = false;
     // blocked (time-parallel) Viterbi, generic_blocked.hip
-    bool blocked = false, blk_cols_lds = true, blk_tail_lds = true;
+    bool blocked = false, blk_cols_lds = true, blk_tail_lds = true, blk_onecol = false;
     int64_t B = 0, H = 0, nblk = 0;
     int ntail = -1;
     double *d_lp0 = nullptr, *d_tlp = nullptr, *d_endv = nullptr, *d_warmv = nullptr;

@@ -55,7 +55,10 @@ def test_reference_viterbi_test_shape(O, H):
     p.close()
 
 
-@pytest.mark.parametrize("N,K,T", [(3, 20, 30011), (2, 33, 4097), (4, 12, 25000)])
+# (3, 58): 9 919 states, one LDS column updated in place; (4, 40): 9 283 states, constants re-read
+# every sample; (4, 45): 11 837 states with more multi-source states
+@pytest.mark.parametrize("N,K,T", [(3, 20, 30011), (2, 33, 4097), (4, 12, 25000), (3, 58, 9000),
+                                   (4, 40, 6000), (4, 45, 5000)])
 def test_overlap_shapes(O, H, N, K, T):
     temps = _templates(H, K, N)
     pp = [0.01, 0.006, 0.008, 0.005][:N]
@@ -105,4 +108,33 @@ def test_warmup_too_short_is_flagged_and_escalated(O, H):
     torch.cuda.synchronize()
     d = p.diagnostics()
     assert d[0] > 0 and d[2] > 1e-6
+    p.close()
+
+
+def test_set_model_on_a_blocked_plan(O, H):
+    import torch
+    from hmmsort_amd import device
+    temps = _templates(H, 30, 2)
+    pp = [0.008, 0.004]
+    sm = H.StateMatrix.create(2, 30, np.log(pp), True)
+    y = H.create_signal(40000, 0.3, pp, temps, seed=21)
+    p = device.Plan(len(y), sm, temps, 0.3)
+    dy = torch.from_numpy(y).cuda()
+    dx = torch.zeros(len(y), dtype=torch.int16, device="cuda")
+    dll = torch.zeros(1, dtype=torch.float64, device="cuda")
+    p.viterbi(dy, dx, dll)
+    x1 = dx.cpu().numpy().copy()
+    # new model of the same shape: other firing rates, scaled templates, other sigma
+    pp2 = [0.002, 0.012]
+    sm2 = H.StateMatrix.create(2, 30, np.log(pp2), True)
+    t2 = np.asfortranarray(temps * 0.8)
+    p.set_model(sm2, t2, 0.35)
+    p.viterbi(dy, dx, dll)
+    torch.cuda.synchronize()
+    x2, ll2 = dx.cpu().numpy(), float(dll.cpu()[0])
+    xo1, _ = O.viterbi(y, to_oracle_sm(O, sm), temps, 0.3)
+    xo2, llo2 = O.viterbi(y, to_oracle_sm(O, sm2), t2, 0.35)
+    assert np.array_equal(x1, xo1) and np.array_equal(x2, xo2)
+    assert abs(ll2 - llo2) <= LL_RTOL * abs(llo2)
+    assert p.diagnostics()[0] == 0
     p.close()
