@@ -282,7 +282,13 @@ def main():
         per = (time.perf_counter() - t) / n_iter
         em.close()
         return per * 1e3, float(o[K * N])
-    em_ms, em_sigma = em_iterations() if not args.time_sharded else (None, None)
+    try:
+        em_ms, em_sigma = em_iterations() if not args.time_sharded else (None, None)
+    except H.HmmsortError as exc:
+        # a template whose firing probability reaches 0 loses its entry transitions (the reference
+        # keeps finite entries only, types.jl:121): the list length changes and the plan must be
+        # rebuilt by the host, which this fixed-shape loop does not do
+        em_ms, em_sigma = None, "stopped: %s" % exc
 
     # ---- several channels per GPU, one plan + one stream each (the serving shape of a multi-
     # channel probe; untimed extra, reported in detail only) ----
@@ -315,9 +321,11 @@ def main():
     # test/runtests.jl:17-34 -- 2 templates, K=60, allow_overlaps=true, 3600 states -- through the
     # blocked engine, device-resident (untimed extra, rank 0 of a 1-GPU run only) ----
     def overlap_decode(To=2_000_000):
-        t2 = np.asfortranarray(temps[:, :2])
+        Ko = 60
+        t2 = np.asfortranarray(np.stack([H.create_spike_template(Ko, 3.0, 0.8, 0.2),
+                                         H.create_spike_template(Ko, 4.0, 0.3, 0.2)], 1))
         ppo = [0.003, 0.001]
-        smo = H.StateMatrix.create(2, K, np.log(ppo), True)
+        smo = H.StateMatrix.create(2, Ko, np.log(ppo), True)
         yo = torch.from_numpy(H.create_signal(To, sigma, ppo, t2, seed=seed + 7)).to(dev)
         xo = torch.zeros(To, dtype=torch.int16, device=dev)
         po = H.Plan(To, smo, t2, sigma)
@@ -330,11 +338,11 @@ def main():
         per = (time.perf_counter() - t) / 3
         d = po.diagnostics(stream)
         po.close()
-        return {"model": "N=2 K=%d allow_overlaps=true, %d states" % (K, smo.nstates), "samples": To,
+        return {"model": "N=2 K=%d allow_overlaps=true, %d states" % (Ko, smo.nstates), "samples": To,
                 "engine": {1: "strict", 2: "ring", 3: "blocked"}.get(io["engine"], io["engine"]),
                 "block": io["block"], "halo": io["halo"], "Msamples_s": To / per / 1e6,
                 "boundary_check_fails": d[0], "max_boundary_spread": d[2]}
-    ov = overlap_decode() if (rank == 0 and world == 1 and K >= 17) else None
+    ov = overlap_decode() if (rank == 0 and world == 1) else None
 
     if rank == 0:
         ms = dt / args.steps * 1e3

@@ -473,6 +473,93 @@ __global__ __launch_bounds__(512) void k_gsum_lds(RingGeom g, int nkb, const dou
         }
 }
 
+// Matrix-core variant of k_gsum for many long rings (BASELINE config 5, where the statistics are
+// the second largest kernel): the spike-triggered sums are a matrix product over time,
+//     G1[k][a] = sum_t y(t+k-1) * rho_a(t),   G2[k][a] = sum_t y(t+k-1)^2 * rho_a(t),
+// i.e. C[16 lags x 16 rings] += A[16 lags x 4 samples] * B[4 samples x 16 rings] per
+// v_mfma_f64_16x16x4_f64, with A a Toeplitz window of y (lane l: y[t0 + (l>>4) + lag0 + (l&15)])
+// and B the posteriors (lane l: rho_{l&15}(t0 + (l>>4)); rings N..15 are zero padding).
+// One workgroup = the same 64 chain columns as k_gsum_lds (so the partials land in the same
+// layout), swept as 8 groups of 8 adjacent columns; a tile of 32 onset rows of rho and the rows of
+// y it touches are staged through LDS ([col][row][ring] resp. [col][row]); wave w owns lag tiles
+// w*tpw .. w*tpw+tpw-1 (two accumulator tiles each: y and y^2) for every column and row.
+// C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg.
+typedef double gs_d4 __attribute__((ext_vector_type(4)));
+constexpr int kGmTR = 32, kGmCW = 8;
+
+template <int N>
+__global__ __launch_bounds__(256) void k_gsum_mfma(RingGeom g, int ntile, const double *__restrict__ yT,
+                                                   const double *__restrict__ rhoT,
+                                                   double *__restrict__ partG)
+{
+    constexpr int TR = kGmTR, CW = kGmCW, RS = TR * 16 + 2;
+    extern __shared__ double lds[];
+    const int B = g.B, L = g.L, ncol = g.ncol;
+    const int tpw = (ntile + 3) / 4;       // lag tiles per wave, <= 4
+    const int YR = TR + ntile * 16 + 1;    // staged y rows per column (odd stride)
+    double *lr = lds;                      // [CW][RS]: rho, ring fastest
+    double *ly = lds + CW * RS;            // [CW][YR]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t planeR = (int64_t)B * ncol;
+    gs_d4 c1[4], c2[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { c1[q] = gs_d4{0.0, 0.0, 0.0, 0.0}; c2[q] = gs_d4{0.0, 0.0, 0.0, 0.0}; }
+    const int lk = lane >> 4, li = lane & 15;
+    for (int sub = 0; sub < 64 / CW; sub++) {
+        const int c0 = blockIdx.x * 64 + sub * CW;
+        for (int s0 = 0; s0 < B; s0 += TR) {
+            __syncthreads();  // the previous tile has been consumed
+            for (int i = tid; i < 16 * TR * CW; i += 256) {
+                const int cc = i % CW, rest = i / CW, u = rest % TR, a = rest / TR;
+                double v = 0.0;
+                if (a < N) v = rhoT[a * planeR + (int64_t)(s0 + u) * ncol + c0 + cc];
+                lr[cc * RS + u * 16 + a] = v;
+            }
+            for (int i = tid; i < CW * (YR - 1); i += 256) {
+                const int cc = i % CW, rr = i / CW, r = s0 + rr, col = c0 + cc;
+                const bool ok = col < g.nch && (int64_t)col * B + r < g.T;
+                const int rq = ok ? r : 0, cq = ok ? col : 0;
+                const int64_t o = (rq < B) ? (int64_t)rq * ncol + cq : (int64_t)(rq - B) * ncol + cq + 1;
+                const double v = yT[o];
+                ly[cc * YR + rr] = ok ? v : 0.0;
+            }
+            __syncthreads();
+            for (int cc = 0; cc < CW; cc++) {
+                const double *lrc = lr + cc * RS + lk * 16 + li;
+                const double *lyc = ly + cc * YR + lk + li + wv * tpw * 16;
+#pragma unroll 2
+                for (int ks = 0; ks < TR / 4; ks++) {
+                    const double b = lrc[ks * 64];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (q < tpw && wv * tpw + q < ntile) {  // wave-uniform
+                            const double a = lyc[4 * ks + q * 16];
+                            c1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1[q], 0, 0, 0);
+                            c2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a * a, b, c2[q], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const int NL = N * L;
+    double *out = partG + (size_t)blockIdx.x * 2 * NL;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int tile = wv * tpw + q;
+        if (q < tpw && tile < ntile && li < N) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int lag = tile * 16 + lk + 4 * r;  // k - 1
+                if (lag < L) {
+                    out[li * L + lag] = c1[q][r];
+                    out[NL + li * L + lag] = c2[q][r];
+                }
+            }
+        }
+    }
+}
+
 // virtual onsets t' = -j (rings already running at the first sample), the end-of-data correction
 // of G0 and pp = gamma[:,1] (baumwelch.jl:263).  One thread per ring state.
 //   extra[0..NL)    = G0 contribution of virtual onsets  +  sum of rho over the onsets of the last
@@ -620,7 +707,17 @@ int ring_estep_post(RingDev *r, const double *d_y, double *d_stats, hipStream_t 
         { PROF(r, "k_fb_check", r->side); hipLaunchKernelGGL((k_fb_check<NN>), dim3(colgroups), dim3(64 * kChkParts), 0, r->side, g, 1e-9, r->P, r->Q,
                            r->A0, r->B0, r->B0h, r->Zc, r->rhoT, r->diag); }
         HS_HIP(hipEventRecord(r->ev_chk, r->side));
-        {
+        const int ntile = (L + 15) / 16;
+        // fp64 MFMA issues at the vector-FMA rate on gfx950, so the matrix-core kernel (rings padded
+        // to 16 columns) only wins where the vector kernel has to re-read rho for many phase groups:
+        // measured at 10-40 M samples: N=16,L=255 21 vs 51 ms; N=12,L=127 4.6 vs 3.0; N=8,L=127 4.3 vs 1.6
+        if (NN >= 9 && L > 160 && ntile <= 16 && g.B % kGmTR == 0 && g.B >= kGmTR + ntile * 16) {
+            const size_t lds = ((size_t)kGmCW * (kGmTR * 16 + 2) + (size_t)kGmCW * (kGmTR + ntile * 16 + 1)) *
+                               sizeof(double);
+            PROF(r, "k_gsum", st);
+            hipLaunchKernelGGL((k_gsum_mfma<NN>), dim3(colgroups), dim3(256), lds, st, g, ntile, r->yT,
+                               r->rhoT, r->partA);
+        } else {
             const int nkb = (L + KB - 1) / KB;
             const size_t lds = ((size_t)NN * 16 * 64 + (size_t)(16 + 8 * KB - 1) * 64) * sizeof(double);
             if (NN * 16 * 64 % 512 == 0 && lds <= 150 * 1024 && g.B % 16 == 0 && g.B >= L + 16 + 8 * KB) {

@@ -42,6 +42,7 @@ def _compare_step(O, H, y, sm, mu, sigma, rtol=1e-8):
     (8, 33, 12_000, 6, 0, 0),
     (16, 40, 10_000, 7, 0, 0),         # 16 rings (BASELINE config 5 ring count)
     (8, 128, 9_000, 8, 0, 0),          # BASELINE config 4 model shape (S = 1017)
+    (10, 180, 9_000, 9, 0, 0),         # many long rings: statistics on the fp64 matrix cores
 ])
 def test_em_step_matches_oracle(O, H, N, K, T, seed, block, halo):
     rng = np.random.default_rng(seed)
@@ -59,6 +60,23 @@ def test_em_step_matches_oracle(O, H, N, K, T, seed, block, halo):
     sm1, mu1, sig1 = _compare_step(O, H, y, sm, mu, 0.4)
     # a second step from the updated model (exercises set-up with the re-estimated lp)
     _compare_step(O, H, y, sm1, mu1, sig1)
+
+
+def test_sixteen_long_rings_one_step(O, H):
+    # 16 rings of 199 states (3185 states; BASELINE config 5 has 16 x 255): every column of the
+    # 16-wide matrix-core statistics tile is a real ring.  One step only: the oracle needs ~10 s.
+    N, K, T = 16, 200, 14_000
+    rng = np.random.default_rng(10)
+    base = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)]
+    amps = [(base[i % 4][0] * (1 + 0.13 * (i // 4)), base[i % 4][1] + 0.03 * (i // 4), base[i % 4][2])
+            for i in range(N)]
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, *a) for a in amps], 1))
+    pp = rng.uniform(2e-4, 3e-4, N)
+    y = H.create_signal(T, 0.3, pp, temps, seed=10)
+    sm = H.StateMatrix.create(N, K, np.log(pp), False)
+    mu = np.asfortranarray(temps * rng.uniform(0.8, 1.1, N)[None, :])
+    mu[0, :] = 0
+    _compare_step(O, H, y, sm, mu, 0.4)
 
 
 def test_random_initialisation_regime(O, H):
