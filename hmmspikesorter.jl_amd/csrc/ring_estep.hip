@@ -487,41 +487,58 @@ __global__ __launch_bounds__(512) void k_gsum_lds(RingGeom g, int nkb, const dou
 typedef double gs_d4 __attribute__((ext_vector_type(4)));
 constexpr int kGmTR = 32, kGmCW = 8;
 
-template <int N>
-__global__ __launch_bounds__(256) void k_gsum_mfma(RingGeom g, int ntile, const double *__restrict__ yT,
+template <int N, int TPW>
+__global__ __launch_bounds__(256) void k_gsum_mfma(RingGeom g, const double *__restrict__ yT,
                                                    const double *__restrict__ rhoT,
                                                    double *__restrict__ partG)
 {
     constexpr int TR = kGmTR, CW = kGmCW, RS = TR * 16 + 2;
     extern __shared__ double lds[];
     const int B = g.B, L = g.L, ncol = g.ncol;
-    const int tpw = (ntile + 3) / 4;       // lag tiles per wave, <= 4
-    const int YR = TR + ntile * 16 + 1;    // staged y rows per column (odd stride)
+    constexpr int tpw = TPW, ntile = 4 * TPW;  // lag tiles per wave / per workgroup, compile time;
+                                               // tiles past L compute lags nobody stores
+    constexpr int YR = TR + ntile * 16 + 1;    // staged y rows per column (odd stride)
     double *lr = lds;                      // [CW][RS]: rho, ring fastest
     double *ly = lds + CW * RS;            // [CW][YR]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t planeR = (int64_t)B * ncol;
-    gs_d4 c1[4], c2[4];
+    gs_d4 c1[TPW], c2[TPW];
 #pragma unroll
-    for (int q = 0; q < 4; q++) { c1[q] = gs_d4{0.0, 0.0, 0.0, 0.0}; c2[q] = gs_d4{0.0, 0.0, 0.0, 0.0}; }
+    for (int q = 0; q < TPW; q++) { c1[q] = gs_d4{0.0, 0.0, 0.0, 0.0}; c2[q] = gs_d4{0.0, 0.0, 0.0, 0.0}; }
     const int lk = lane >> 4, li = lane & 15;
     for (int sub = 0; sub < 64 / CW; sub++) {
         const int c0 = blockIdx.x * 64 + sub * CW;
         for (int s0 = 0; s0 < B; s0 += TR) {
-            __syncthreads();  // the previous tile has been consumed
-            for (int i = tid; i < 16 * TR * CW; i += 256) {
+            constexpr int NRH = 16 * TR * CW / 256, NYM = (CW * (YR - 1) + 255) / 256;
+            double tr_[NRH], ty_[NYM];
+#pragma unroll
+            for (int k = 0; k < NRH; k++) {
+                const int i = tid + k * 256;
                 const int cc = i % CW, rest = i / CW, u = rest % TR, a = rest / TR;
-                double v = 0.0;
-                if (a < N) v = rhoT[a * planeR + (int64_t)(s0 + u) * ncol + c0 + cc];
-                lr[cc * RS + u * 16 + a] = v;
+                const double v = rhoT[a < N ? a * planeR + (int64_t)(s0 + u) * ncol + c0 + cc : 0];
+                tr_[k] = a < N ? v : 0.0;
             }
-            for (int i = tid; i < CW * (YR - 1); i += 256) {
+#pragma unroll
+            for (int k = 0; k < NYM; k++) {
+                const int i = tid + k * 256;
                 const int cc = i % CW, rr = i / CW, r = s0 + rr, col = c0 + cc;
-                const bool ok = col < g.nch && (int64_t)col * B + r < g.T;
+                const bool ok = i < CW * (YR - 1) && col < g.nch && (int64_t)col * B + r < g.T;
                 const int rq = ok ? r : 0, cq = ok ? col : 0;
                 const int64_t o = (rq < B) ? (int64_t)rq * ncol + cq : (int64_t)(rq - B) * ncol + cq + 1;
                 const double v = yT[o];
-                ly[cc * YR + rr] = ok ? v : 0.0;
+                ty_[k] = ok ? v : 0.0;
+            }
+            __syncthreads();  // the previous tile has been consumed
+#pragma unroll
+            for (int k = 0; k < NRH; k++) {
+                const int i = tid + k * 256;
+                const int cc = i % CW, rest = i / CW, u = rest % TR, a = rest / TR;
+                lr[cc * RS + u * 16 + a] = tr_[k];
+            }
+#pragma unroll
+            for (int k = 0; k < NYM; k++) {
+                const int i = tid + k * 256;
+                if (i < CW * (YR - 1)) ly[(i % CW) * YR + i / CW] = ty_[k];
             }
             __syncthreads();
             for (int cc = 0; cc < CW; cc++) {
@@ -531,12 +548,10 @@ __global__ __launch_bounds__(256) void k_gsum_mfma(RingGeom g, int ntile, const 
                 for (int ks = 0; ks < TR / 4; ks++) {
                     const double b = lrc[ks * 64];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        if (q < tpw && wv * tpw + q < ntile) {  // wave-uniform
-                            const double a = lyc[4 * ks + q * 16];
-                            c1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1[q], 0, 0, 0);
-                            c2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a * a, b, c2[q], 0, 0, 0);
-                        }
+                    for (int q = 0; q < TPW; q++) {
+                        const double a = lyc[4 * ks + q * 16];
+                        c1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1[q], 0, 0, 0);
+                        c2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a * a, b, c2[q], 0, 0, 0);
                     }
                 }
             }
@@ -545,9 +560,9 @@ __global__ __launch_bounds__(256) void k_gsum_mfma(RingGeom g, int ntile, const 
     const int NL = N * L;
     double *out = partG + (size_t)blockIdx.x * 2 * NL;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < TPW; q++) {
         const int tile = wv * tpw + q;
-        if (q < tpw && tile < ntile && li < N) {
+        if (li < N) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int lag = tile * 16 + lk + 4 * r;  // k - 1
@@ -557,6 +572,123 @@ __global__ __launch_bounds__(256) void k_gsum_mfma(RingGeom g, int ntile, const 
                 }
             }
         }
+    }
+}
+
+// Matrix-core statistics for FEW rings (N <= 8; the headline model has 4): the 16 columns of the
+// B operand hold NS = 16/NP copies of the NP (= N rounded up to a power of two) rings, copy s
+// delayed by 16*s samples,
+//     B[kk][a + NP*s] = rho_a(tau + kk - 16 s),   A[i][kk] = y(tau + kk + i + LPT*q)
+//     C[i][a + NP*s] += ...  =  sum over onsets t = tau + kk - 16 s of rho_a(t) * y(t + 16 s + i + LPT*q),
+// so one v_mfma_f64_16x16x4_f64 accumulates LPT = 16*NS consecutive lags of every ring with no
+// padded column (N = 4, L = 59: all 59 lags of all 4 rings in ONE accumulator tile, 92 % useful).
+// tau sweeps rows 0 .. B-1+16(NS-1) of a chain column; rho rows outside [0, B) are staged as zeros.
+// Workgroup = the 64 columns of k_gsum_lds (same partial layout) as 8 groups of 8 adjacent columns;
+// a tile of TR tau-rows is staged through LDS (rho [col][row][ring], y [col][row]) by all 4 waves,
+// wave w then sweeps columns 2w, 2w+1.  The four waves' accumulators are summed through LDS.
+template <int N, int NT>
+__global__ __launch_bounds__(256) void k_gsum_mx(RingGeom g, const double *__restrict__ yT,
+                                                 const double *__restrict__ rhoT,
+                                                 double *__restrict__ partG)
+{
+    constexpr int NP = N <= 1 ? 1 : (N <= 2 ? 2 : (N <= 4 ? 4 : 8));
+    constexpr int NS = 16 / NP, LPT = 16 * NS, HS = 16 * (NS - 1);
+    constexpr int TR = 64, CW = 8, RR = TR + HS;  // staged rho rows per tile
+    extern __shared__ double lds[];
+    constexpr int ntile = NT;                      // accumulator tiles of LPT lags, compile time:
+                                                   // a run-time count makes the compiler shuffle
+                                                   // all tiles through AGPRs around every MFMA
+    const int B = g.B, L = g.L, ncol = g.ncol;
+    constexpr int YR = TR + 19 + LPT * (NT - 1);   // staged y rows per column (odd)
+    constexpr int RS = RR * NP + 2;                // rho column stride
+    double *lr = lds;                              // [CW][RS]
+    double *ly = lds + CW * RS;                    // [CW][YR]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lk = lane >> 4, lj = lane & 15, la = lj % NP, lsft = lj / NP;
+    const int64_t planeR = (int64_t)B * ncol;
+    gs_d4 c1[NT], c2[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++) { c1[q] = gs_d4{0.0, 0.0, 0.0, 0.0}; c2[q] = gs_d4{0.0, 0.0, 0.0, 0.0}; }
+    for (int sub = 0; sub < 64 / CW; sub++) {
+        const int c0 = blockIdx.x * 64 + sub * CW;
+        for (int s0 = 0; s0 < B + HS; s0 += TR) {
+            // all global loads of the tile are issued back to back into registers, then stored
+            constexpr int NRH = (NP * RR * CW + 255) / 256, NYM = (CW * (YR - 1) + 255) / 256;
+            double tr_[NRH], ty_[NYM];
+#pragma unroll
+            for (int k = 0; k < NRH; k++) {   // rho rows s0-HS .. s0+TR-1
+                const int i = tid + k * 256;
+                const int cc = i % CW, rest = i / CW, u = rest % RR, a = rest / RR;
+                const int row = s0 - HS + u;
+                const bool ok = i < NP * RR * CW && a < N && row >= 0 && row < B;
+                const double v = rhoT[ok ? a * planeR + (int64_t)row * ncol + c0 + cc : 0];
+                tr_[k] = ok ? v : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < NYM; k++) {   // y rows s0 .. s0+YR-2
+                const int i = tid + k * 256;
+                const int cc = i % CW, rr = i / CW, r = s0 + rr, col = c0 + cc;
+                const bool ok = i < CW * (YR - 1) && col < g.nch && (int64_t)col * B + r < g.T;
+                const int rq = ok ? r : 0, cq = ok ? col : 0;
+                const int64_t o = (rq < B) ? (int64_t)rq * ncol + cq
+                                           : (rq < 2 * B ? (int64_t)(rq - B) * ncol + cq + 1
+                                                         : (int64_t)(rq - 2 * B) * ncol + cq + 2);
+                const double v = yT[o];
+                ty_[k] = ok ? v : 0.0;
+            }
+            __syncthreads();  // the previous tile has been consumed
+#pragma unroll
+            for (int k = 0; k < NRH; k++) {
+                const int i = tid + k * 256;
+                const int cc = i % CW, rest = i / CW, u = rest % RR, a = rest / RR;
+                if (i < NP * RR * CW) lr[cc * RS + u * NP + a] = tr_[k];
+            }
+#pragma unroll
+            for (int k = 0; k < NYM; k++) {
+                const int i = tid + k * 256;
+                if (i < CW * (YR - 1)) ly[(i % CW) * YR + i / CW] = ty_[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < CW / 4; h++) {
+                const int cc = wv * (CW / 4) + h;
+                const double *lrc = lr + cc * RS + (lk - 16 * lsft + HS) * NP + la;
+                const double *lyc = ly + cc * YR + lk + lj;
+#pragma unroll 4
+                for (int ts = 0; ts < TR / 4; ts++) {
+                    const double b = lrc[ts * 4 * NP];
+#pragma unroll
+                    for (int q = 0; q < NT; q++) {
+                        const double a = lyc[ts * 4 + q * LPT];
+                        c1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1[q], 0, 0, 0);
+                        c2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a * a, b, c2[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // sum the four waves' tiles: LDS [wave][ntile][2][4 regs][64 lanes]
+    __syncthreads();
+    double *red = lds;
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            red[(((wv * ntile + q) * 2 + 0) * 4 + r) * 64 + lane] = c1[q][r];
+            red[(((wv * ntile + q) * 2 + 1) * 4 + r) * 64 + lane] = c2[q][r];
+        }
+    }
+    __syncthreads();
+    const int NL = N * L;
+    double *out = partG + (size_t)blockIdx.x * 2 * NL;
+    for (int e = tid; e < ntile * 2 * 4 * 64; e += 256) {
+        const int ln = e & 63, r = (e >> 6) & 3, which = (e >> 8) & 1, q = e >> 9;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) v += red[(((w * ntile + q) * 2 + which) * 4 + r) * 64 + ln];
+        const int j = ln & 15, a = j % NP, sft = j / NP;
+        const int lag = q * LPT + 16 * sft + (ln >> 4) + 4 * r;
+        if (a < N && lag < L) out[which * NL + a * L + lag] = v;
     }
 }
 
@@ -708,15 +840,40 @@ int ring_estep_post(RingDev *r, const double *d_y, double *d_stats, hipStream_t 
                            r->A0, r->B0, r->B0h, r->Zc, r->rhoT, r->diag); }
         HS_HIP(hipEventRecord(r->ev_chk, r->side));
         const int ntile = (L + 15) / 16;
+        constexpr int NPx = NN <= 1 ? 1 : (NN <= 2 ? 2 : (NN <= 4 ? 4 : 8));
+        constexpr int LPTx = 16 * (16 / NPx), HSx = LPTx - 16;
+        const int ntx = (L + LPTx - 1) / LPTx;
+        // measured at 10 M samples against k_gsum_lds: N=4,L=59 0.39 vs 0.55 ms; N=2,L=59 0.41 vs 0.22;
+        // N=8,L=127 1.80 vs 1.56 -> used for 3-4 rings (the headline model)
+        if (NPx == 4 && ntx <= 4 && g.B % 64 == 0 && 2 * g.B >= 64 + 19 + LPTx * ntx + HSx) {
+            const size_t l1 = ((size_t)8 * ((64 + HSx) * NPx + 2) + (size_t)8 * (64 + 19 + LPTx * (ntx - 1))) * 8;
+            const size_t l2 = (size_t)4 * ntx * 2 * 4 * 64 * 8;
+            const size_t lds = l1 > l2 ? l1 : l2;
+            constexpr int NM = NN <= 8 ? NN : 8;
+            auto go = [&](auto kern) -> int {
+                if (lds > 64 * 1024)
+                    HS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds));
+                PROF(r, "k_gsum", st);
+                hipLaunchKernelGGL(kern, dim3(colgroups), dim3(256), lds, st, g, r->yT, r->rhoT, r->partA);
+                return HMMSORT_OK;
+            };
+            int rc2 = ntx == 1 ? go(k_gsum_mx<NM, 1>) : ntx == 2 ? go(k_gsum_mx<NM, 2>)
+                    : ntx == 3 ? go(k_gsum_mx<NM, 3>) : go(k_gsum_mx<NM, 4>);
+            if (rc2) return rc2;
+        } else
         // fp64 MFMA issues at the vector-FMA rate on gfx950, so the matrix-core kernel (rings padded
         // to 16 columns) only wins where the vector kernel has to re-read rho for many phase groups:
         // measured at 10-40 M samples: N=16,L=255 21 vs 51 ms; N=12,L=127 4.6 vs 3.0; N=8,L=127 4.3 vs 1.6
-        if (NN >= 9 && L > 160 && ntile <= 16 && g.B % kGmTR == 0 && g.B >= kGmTR + ntile * 16) {
-            const size_t lds = ((size_t)kGmCW * (kGmTR * 16 + 2) + (size_t)kGmCW * (kGmTR + ntile * 16 + 1)) *
+        if (NN >= 9 && L > 160 && ntile <= 16 && g.B % kGmTR == 0 && g.B >= kGmTR + ((ntile + 3) / 4) * 64) {
+            const int tpw = (ntile + 3) / 4;
+            const size_t lds = ((size_t)kGmCW * (kGmTR * 16 + 2) + (size_t)kGmCW * (kGmTR + 4 * tpw * 16 + 1)) *
                                sizeof(double);
             PROF(r, "k_gsum", st);
-            hipLaunchKernelGGL((k_gsum_mfma<NN>), dim3(colgroups), dim3(256), lds, st, g, ntile, r->yT,
-                               r->rhoT, r->partA);
+            if (tpw == 1) hipLaunchKernelGGL((k_gsum_mfma<NN, 1>), dim3(colgroups), dim3(256), lds, st, g, r->yT, r->rhoT, r->partA);
+            else if (tpw == 2) hipLaunchKernelGGL((k_gsum_mfma<NN, 2>), dim3(colgroups), dim3(256), lds, st, g, r->yT, r->rhoT, r->partA);
+            else if (tpw == 3) hipLaunchKernelGGL((k_gsum_mfma<NN, 3>), dim3(colgroups), dim3(256), lds, st, g, r->yT, r->rhoT, r->partA);
+            else hipLaunchKernelGGL((k_gsum_mfma<NN, 4>), dim3(colgroups), dim3(256), lds, st, g, r->yT, r->rhoT, r->partA);
         } else {
             const int nkb = (L + KB - 1) / KB;
             const size_t lds = ((size_t)NN * 16 * 64 + (size_t)(16 + 8 * KB - 1) * 64) * sizeof(double);
