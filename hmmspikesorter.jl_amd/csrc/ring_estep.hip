@@ -586,6 +586,7 @@ __global__ __launch_bounds__(256) void k_gsum_mfma(RingGeom g, const double *__r
 // Workgroup = the 64 columns of k_gsum_lds (same partial layout) as 8 groups of 8 adjacent columns;
 // a tile of TR tau-rows is staged through LDS (rho [col][row][ring], y [col][row]) by all 4 waves,
 // wave w then sweeps columns 2w, 2w+1.  The four waves' accumulators are summed through LDS.
+constexpr int kGxTR = 64;
 template <int N, int NT>
 __global__ __launch_bounds__(256) void k_gsum_mx(RingGeom g, const double *__restrict__ yT,
                                                  const double *__restrict__ rhoT,
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(256) void k_gsum_mx(RingGeom g, const double *__res
 {
     constexpr int NP = N <= 1 ? 1 : (N <= 2 ? 2 : (N <= 4 ? 4 : 8));
     constexpr int NS = 16 / NP, LPT = 16 * NS, HS = 16 * (NS - 1);
-    constexpr int TR = 64, CW = 8, RR = TR + HS;  // staged rho rows per tile
+    constexpr int TR = kGxTR, CW = 8, RR = TR + HS;  // staged rho rows per tile
     extern __shared__ double lds[];
     constexpr int ntile = NT;                      // accumulator tiles of LPT lags, compile time:
                                                    // a run-time count makes the compiler shuffle
@@ -845,8 +846,8 @@ int ring_estep_post(RingDev *r, const double *d_y, double *d_stats, hipStream_t 
         const int ntx = (L + LPTx - 1) / LPTx;
         // measured at 10 M samples against k_gsum_lds: N=4,L=59 0.39 vs 0.55 ms; N=2,L=59 0.41 vs 0.22;
         // N=8,L=127 1.80 vs 1.56 -> used for 3-4 rings (the headline model)
-        if (NPx == 4 && ntx <= 4 && g.B % 64 == 0 && 2 * g.B >= 64 + 19 + LPTx * ntx + HSx) {
-            const size_t l1 = ((size_t)8 * ((64 + HSx) * NPx + 2) + (size_t)8 * (64 + 19 + LPTx * (ntx - 1))) * 8;
+        if (NPx == 4 && ntx <= 4 && g.B % 64 == 0 && 2 * g.B >= kGxTR + 19 + LPTx * ntx + HSx) {
+            const size_t l1 = ((size_t)8 * ((kGxTR + HSx) * NPx + 2) + (size_t)8 * (kGxTR + 19 + LPTx * (ntx - 1))) * 8;
             const size_t l2 = (size_t)4 * ntx * 2 * 4 * 64 * 8;
             const size_t lds = l1 > l2 ? l1 : l2;
             constexpr int NM = NN <= 8 ? NN : 8;
