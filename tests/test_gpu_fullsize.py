@@ -126,3 +126,30 @@ def test_device_resident_em_loop(O, H):
         assert np.array_equal(mu_d, mu_h) and sig_d == sig_h
         assert np.array_equal(sm_d.transitions["lp"], sm_h.transitions["lp"])
     plan.close()
+
+
+def test_overlap_decode_blocked_equals_strict_at_2M(H):
+    # the reference's Viterbi-test model (test/runtests.jl:17-34: N=2, K=60, overlaps on, 3600
+    # states) at 2 M samples: time-parallel blocked engine vs the op-for-op single sweep
+    K, To = 60, 2_000_000
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, 3.0, 0.8, 0.2),
+                                        H.create_spike_template(K, 4.0, 0.3, 0.2)], 1))
+    pp = [0.003, 0.001]
+    sm = H.StateMatrix.create(2, K, np.log(pp), True)
+    y = H.create_signal(To, 0.3, pp, temps, seed=77)
+    # make sure overlapping spikes occur: add a second template on top of some generated spikes
+    rng = np.random.default_rng(5)
+    for t0 in rng.integers(1000, To - 1000, 200):
+        y[t0:t0 + K] += temps[:, 0]
+        y[t0 + 17:t0 + 17 + K] += temps[:, 1]
+    H.set_option("engine", H.ENGINE_AUTO)
+    x, ll = H.viterbi(y, sm, temps, 0.3)               # AUTO -> blocked for an overlap model
+    assert H.get_option("last_escalations") == 0
+    H.set_option("engine", H.ENGINE_STRICT)
+    xs, lls = H.viterbi(y, sm, temps, 0.3)
+    H.set_option("engine", H.ENGINE_AUTO)
+    assert np.array_equal(x, xs)
+    assert abs(ll - lls) <= 1e-9 * abs(lls)
+    assert (x > 1 + 2 * (K - 1)).sum() > 200 * 20      # pair states were decoded
+    Y = H.reconstruct_signal(x, sm, temps, 0.3)
+    assert abs(np.std(Y - y) - 0.3) < 0.01
