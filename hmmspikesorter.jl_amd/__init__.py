@@ -12,10 +12,11 @@ from .api import (HMMSpikeTemplateModel, HMMSpikingModel, StateMatrix, backward,
                   predict, reconstruct_signal, train_model, train_step, unroll_mlseq, update,
                   viterbi)
 from .device import Plan
+from .sortdata import get_lp, sort_data
 from .synth import create_signal, create_spike_template
 
 __all__ = ["StateMatrix", "HMMSpikeTemplateModel", "HMMSpikingModel", "forward", "backward",
            "update", "train_model", "train_step", "viterbi", "reconstruct_signal", "unroll_mlseq",
            "fit", "predict", "extract_spiketimes", "Plan", "create_signal", "create_spike_template", "HmmsortError",
            "set_option", "get_option", "device_count", "ENGINE_AUTO", "ENGINE_STRICT",
-           "ENGINE_RING", "ENGINE_BLOCKED"]
+           "ENGINE_RING", "ENGINE_BLOCKED", "get_lp", "sort_data"]
