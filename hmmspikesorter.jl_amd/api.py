@@ -276,23 +276,44 @@ def fit(templates, X, chunksize=None):
     i = j = 1
     ml_seq = np.ones(n, dtype=np.int16)
     ll = 0.0
-    while j < n:
-        j = min(i + chunksize - 1, n)
-        k = j - i + 1
-        l = 1
-        x, _ll = viterbi(X[i - 1:j], lA, mu, sigma)
-        if i > 1:
-            while x[l - 1] > 1:
-                l += 1
-        if j < n:
-            while x[k - 1] > 1:
-                j -= 1
-                k -= 1
-        ml_seq[i + l - 2:j] = x[l - 1:k]
-        ll += _ll
-        if j <= i:
-            raise RuntimeError("chunk without a silent sample: the reference loops forever here")
-        i = j
+    # The chunks depend on each other (a chunk restarts where the previous decode was last silent),
+    # so they run one after the other -- but on the device: the signal is uploaded once and one
+    # plan per chunk length is reused (the host-buffer entry point would rebuild its plan and copy
+    # the chunk for every call).
+    import torch
+    from .device import Plan
+    dX = torch.from_numpy(X).cuda()
+    dx = torch.zeros(min(chunksize, n), dtype=torch.int16, device="cuda")
+    dll = torch.zeros(1, dtype=torch.float64, device="cuda")
+    plans = {}
+    try:
+        while j < n:
+            j = min(i + chunksize - 1, n)
+            k = j - i + 1
+            l = 1
+            if k not in plans:
+                plans[k] = Plan(k, lA, mu, sigma)
+            plan = plans[k]
+            plan.viterbi(dX.data_ptr() + (i - 1) * 8, dx, dll)
+            if plan.diagnostics()[0] != 0:      # a block boundary failed its warm-up check:
+                x, _ll = viterbi(X[i - 1:j], lA, mu, sigma)   # the escalating entry point
+            else:
+                x, _ll = dx[:k].cpu().numpy(), float(dll.cpu()[0])
+            if i > 1:
+                while x[l - 1] > 1:
+                    l += 1
+            if j < n:
+                while x[k - 1] > 1:
+                    j -= 1
+                    k -= 1
+            ml_seq[i + l - 2:j] = x[l - 1:k]
+            ll += _ll
+            if j <= i:
+                raise RuntimeError("chunk without a silent sample: the reference loops forever here")
+            i = j
+    finally:
+        for pl in plans.values():
+            pl.close()
     return HMMSpikingModel(templates, ml_seq, ll, X)
 
 
