@@ -185,6 +185,59 @@ def train_step(X, state_matrix, mu0, sigma0, verbose=0):
     return _finish_step(state_matrix, mu_f, sig, lp, nlp, pp)
 
 
+class _EMSession:
+    """EM steps on one signal that stays in HBM: the signal is uploaded once and one plan is
+    re-armed with hmmsort_plan_set_model between steps (ring-engine models; anything else, a
+    changed model shape or a failed warm-up certificate goes through train_step, which escalates)."""
+
+    def __init__(self, X):
+        self.X = X
+        self.dX = None
+        self.plan = None
+        self.key = None
+
+    def close(self):
+        if self.plan is not None:
+            self.plan.close()
+            self.plan = None
+
+    def step(self, lA, mu, sigma, verbose=0):
+        import torch
+        from . import _lib
+        from .device import Plan
+        key = (lA.N, lA.K, lA.nstates, len(lA.transitions), lA.resolve_overlaps)
+        try:
+            if self.key != key:                 # first step, or the model shape changed
+                self.close()
+                self.key = key
+                self.plan = Plan(len(self.X), lA, mu, sigma)
+                if self.plan.info()["engine"] != _lib.ENGINE_RING:
+                    self.close()                # remembered through self.key: not retried
+            elif self.plan is not None:
+                self.plan.set_model(lA, mu, sigma)
+        except _lib.HmmsortError:
+            self.close()
+        if self.plan is None:
+            return train_step(self.X, lA, mu, sigma, verbose=verbose)
+        if self.dX is None:
+            self.dX = torch.from_numpy(self.X).cuda()
+            self.stats = torch.zeros(self.plan.stats_len(), dtype=torch.float64, device="cuda")
+        out = torch.zeros(self.plan.mstep_len(), dtype=torch.float64, device="cuda")
+        self.plan.estep(self.dX, self.stats)
+        self.plan.mstep(self.stats, out)
+        d = self.plan.diagnostics()
+        if d[3] != 0 or d[5] != 0:
+            return train_step(self.X, lA, mu, sigma, verbose=verbose)
+        o = out.cpu().numpy()
+        K, N = lA.K, lA.N
+        mu_n = np.asfortranarray(o[:K * N].reshape((K, N), order="F"))
+        if isinstance(mu, np.ndarray) and mu.shape == mu_n.shape and mu.dtype == np.float64:
+            mu[...] = mu_n  # the reference updates the caller's mu in place (baumwelch.jl:268)
+        lA_n = StateMatrix.from_states(lA.states, o[K * N + 1 + N:], K, o[K * N + 1:K * N + 1 + N],
+                                       lA.resolve_overlaps)
+        return lA_n, mu_n, float(o[K * N])
+
+
 def train_model(X, *args, callback=None, verbose=0, p0=None, rng=None, postprocess=None):
     """The three `train_model` methods of baumwelch.jl:
 
@@ -206,16 +259,20 @@ def train_model(X, *args, callback=None, verbose=0, p0=None, rng=None, postproce
         nsteps = int(args[3])
         cb = args[4] if len(args) > 4 else callback
         mu = np.array(mu, dtype=np.float64, order="F", copy=True)
-        for _ in range(nsteps):
-            if cb is not None:
-                cb(mu)
-            state_matrix, mu, sigma = train_step(X, state_matrix, mu, sigma, verbose=verbose)
-            if state_matrix.isempty():
-                break
-        if postprocess is not None:
-            state_matrix, mu = postprocess(state_matrix, mu, sigma)
-        for _ in range(nsteps // 2):
-            state_matrix, mu, sigma = train_step(X, state_matrix, mu, sigma, verbose=verbose)
+        em = _EMSession(X)
+        try:
+            for _ in range(nsteps):
+                if cb is not None:
+                    cb(mu)
+                state_matrix, mu, sigma = em.step(state_matrix, mu, sigma, verbose=verbose)
+                if state_matrix.isempty():
+                    break
+            if postprocess is not None:
+                state_matrix, mu = postprocess(state_matrix, mu, sigma)
+            for _ in range(nsteps // 2):
+                state_matrix, mu, sigma = em.step(state_matrix, mu, sigma, verbose=verbose)
+        finally:
+            em.close()
         return state_matrix, mu, sigma
     # random initialisation, baumwelch.jl:311-322
     N = int(args[0]) if len(args) > 0 else 3

@@ -215,3 +215,23 @@ def test_time_sharded_estep_equals_whole_recording(O, H):
     assert np.allclose(o[:K * N].reshape((K, N), order="F"), omu, rtol=1e-8, atol=1e-11)
     assert abs(o[K * N] - osig) <= 1e-8 * osig and np.allclose(o[K * N + 1:K * N + 1 + N], olp, rtol=1e-8)
     whole.close()
+
+
+def test_train_model_loop_stays_on_device(O, H):
+    # baumwelch.jl:324-354 through the EM session (signal uploaded once, plan re-armed per step):
+    # nsteps + nsteps//2 steps, callback(mu) before each of the first nsteps
+    K, N, T = 30, 2, 20_000
+    temps = two_templates(H, K)
+    pp = [0.004, 0.003]
+    y = H.create_signal(T, 0.3, pp, temps, seed=12)
+    sm = H.StateMatrix.create(N, K, np.log(pp), False)
+    mu0 = np.asfortranarray(temps * 0.85)
+    mu0[0, :] = 0
+    seen = []
+    sm_n, mu_n, sig_n = H.train_model(y, sm, mu0, 0.4, 2, lambda m: seen.append(m.copy()))
+    osm, omu, osig = to_oracle_sm(O, sm), mu0.copy(order="F"), 0.4
+    for _ in range(3):
+        osm, omu, osig, _, _ = O.train_step(y, osm, omu, osig)
+    assert len(seen) == 2 and np.array_equal(seen[0], mu0)
+    assert np.allclose(mu_n, omu, rtol=1e-8, atol=1e-11) and abs(sig_n - osig) <= 1e-8 * osig
+    assert np.allclose(sm_n.transitions["lp"], osm.val, rtol=1e-8, atol=1e-12)
