@@ -84,6 +84,12 @@ int plan_create_engine(hmmsort_plan **out, int64_t T, const int16_t *states, int
         p->engine = HMMSORT_ENGINE_BLOCKED;
         rc = generic_create(&p->gen, p->model, T, true, options().block,
                             halo_req >= 0 ? halo_req : options().halo);
+        if (rc == HMMSORT_EUNSUP && engine_req == HMMSORT_ENGINE_AUTO) {
+            // a list the blocked sweep does not take (in-degree > 256): op-for-op single sweep
+            p->engine = HMMSORT_ENGINE_STRICT;
+            p->gen = nullptr;
+            rc = generic_create(&p->gen, p->model, T);
+        }
     } else {
         p->engine = HMMSORT_ENGINE_STRICT;
         rc = generic_create(&p->gen, p->model, T);

@@ -33,7 +33,6 @@ struct RingGeom {
     int B, H;      // chain length, warm-up length (multiples of 64, H <= B)
     int nch;       // chains = ceil(T/B); every chain has >= L samples
     int ncol;      // columns of the transposed arrays (nch rounded up to 64)
-    int Lc;        // (unused)
     int bits, epw, W;  // psi packing: bits per entry, entries per 32-bit word, words per sample
     // time shard of a longer recording (hmmsort_plan_set_shard): statistics are accumulated for
     // the owned samples/onsets [own_lo, own_hi) only; first/last: the shard starts/ends the recording

@@ -50,7 +50,6 @@ static int make_geometry(RingGeom &g, int64_t T, int N, int L, int64_t block_req
     g.B = (int)B; g.H = (int)H;
     g.nch = (int)((T + B - 1) / B);
     g.ncol = (int)round_up(g.nch, 64);
-    g.Lc = 0;
     int bits = 1;
     while ((1 << bits) < N + 1) bits++;
     g.bits = bits; g.epw = 32 / bits; g.W = (N + 1 + g.epw - 1) / g.epw;

@@ -138,3 +138,39 @@ def test_set_model_on_a_blocked_plan(O, H):
     assert abs(ll2 - llo2) <= LL_RTOL * abs(llo2)
     assert p.diagnostics()[0] == 0
     p.close()
+
+
+def test_arbitrary_lists(O, H):
+    # the engines take the caller's list as it is (StateMatrix is a plain container, types.jl:1-9)
+    rng = np.random.default_rng(4)
+    # (a) a hub: every state reaches state 1 and state 1 reaches every state -> in-degree 320, which
+    #     the blocked sweep refuses; AUTO must fall back to the op-for-op single sweep
+    S, T = 320, 5000
+    states = np.asfortranarray(np.arange(1, S + 1, dtype=np.int16)[None, :])
+    tr = ([(1, j, np.log(1.0 / S)) for j in range(1, S + 1)] + [(j, 1, np.log(0.5)) for j in range(2, S + 1)]
+          + [(j, j, np.log(0.5)) for j in range(2, S + 1)])
+    tr.sort(key=lambda e: (e[0], e[1]))             # reference order: source-major, destination ascending
+    sm = H.StateMatrix(states, np.array(tr, dtype=H._lib.TRANS_DTYPE), np.zeros(S), S, 1, S, False)
+    mu = np.asfortranarray(rng.normal(0, 2, (S, 1)))
+    y = rng.normal(0, 1, T) + mu[rng.integers(0, S, T) // 40 * 40, 0]
+    H.set_option("engine", H.ENGINE_AUTO)
+    _check(O, H, y, sm, mu, 0.8)
+    from hmmsort_amd import device
+    p = device.Plan(T, sm, mu, 0.8)
+    assert p.info()["engine"] == H.ENGINE_STRICT
+    p.close()
+    # (b) a sparse random graph with in-degree <= 6 and some unreachable states: blocked sweep
+    S = 700
+    tr = []
+    for j in range(1, S + 1):
+        for d in sorted(set(rng.integers(1, S - 50 + 1, 3).tolist() + [min(j + 1, S)])):
+            tr.append((j, int(d), float(np.log(rng.uniform(0.05, 0.5)))))
+    tr.sort(key=lambda e: (e[0], e[1]))
+    states = np.asfortranarray(np.arange(1, S + 1, dtype=np.int16)[None, :])
+    sm = H.StateMatrix(states, np.array(tr, dtype=H._lib.TRANS_DTYPE), np.zeros(S), S, 1, S, False)
+    mu = np.asfortranarray(rng.normal(0, 1.5, (S, 1)))
+    y = rng.normal(0, 1, 9000)
+    p = device.Plan(len(y), sm, mu, 0.7)
+    assert p.info()["engine"] == H.ENGINE_BLOCKED
+    p.close()
+    _check(O, H, y, sm, mu, 0.7)
