@@ -47,7 +47,7 @@ def test_sort_data_end_to_end(O, H, tmp_path):
     rc, ml, ll = O.fit_chunked(raw.astype(np.float64), to_oracle_sm(O, sm), mu, sigma, 100_000)
     assert rc == 0
     assert np.array_equal(out["mlseq"], O.unroll_mlseq(ml, to_oracle_sm(O, sm)))
-    assert abs(float(out["ll"]) - ll) <= 1e-9 * abs(ll)
-    assert np.allclose(out["waveforms"], mu) and abs(float(out["sigma"]) - sigma) < 1e-9
+    assert abs(out["ll"].item() - ll) <= 1e-9 * abs(ll)
+    assert np.allclose(out["waveforms"], mu) and abs(out["sigma"].item() - sigma) < 1e-9
     assert np.allclose(np.ravel(out["lp"]), H.get_lp(sm)[0])
     assert out["mlseq"].shape == (N, T) and out["mlseq"].max() > 1
