@@ -23,6 +23,7 @@
 // -Inf/NaN, i.e. non-finite data, are the one case where this differs from viterbi.jl:53's
 // ones()).  Per-block columns endv/warmv nblk x S doubles; maps nblk x S int16.
 #include <cmath>
+#include <cstring>
 
 #include "generic_dev.h"
 #include "hmmsort_internal.h"
@@ -82,6 +83,8 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // the incoming transitions after the first one (multi-source states only): viterbi.jl:76-84
+// (a 4-wide batched variant of this loop was measured slower: it costs the registers that keep the
+// sweep at two workgroups per CU)
 template <typename PrevPtr, typename SrcPtr, typename LpPtr>
 __device__ __forceinline__ void block_tail(PrevPtr prev, int ti, SrcPtr tsrc, LpPtr tlp,
                                            double &best, int &arg)
@@ -367,6 +370,90 @@ void gen_vit_block1(BlockArgs a)
     }
     __syncthreads();
     for (int j = tid; j < S; j += nt) a.endv[(int64_t)c * S + j] = col[j];
+}
+
+// Models whose column does not fit LDS at all (N=4, K=60 with overlaps: 21 123 states, the largest
+// the reference's Int16 ids and its CLI default of 4 templates allow): the two columns stay in a
+// per-block global scratch (L2), but the per-state constants are held in registers instead of being
+// re-read every sample -- mean (2 VGPRs) and one packed word: source (15 bits) | index into an LDS
+// dictionary of the distinct first-transition log-probabilities (8 bits; overlap models have a
+// handful) | "has more transitions" flag.  Per sample and workgroup the L2 traffic drops from
+// 40 to 16 bytes per state.  One workgroup per CU, 128 VGPRs.
+template <int SPT>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void gen_vit_blockG(BlockArgs a, const double *__restrict__ lpdict_g, int ndict,
+                    const uint8_t *__restrict__ lpidx)
+{
+    extern __shared__ double sh[];  // dictionary, then the tails
+    constexpr int nt = 1024;  // launch contract; compile-time so that per-state addresses are not hoisted
+    const int c = blockIdx.x, S = a.S, tid = threadIdx.x;
+    double *lpd = sh;
+    double *l_tlp = sh + 256;
+    int32_t *l_tsrc = (int32_t *)(l_tlp + a.ntail);
+    for (int i = tid; i < ndict; i += nt) lpd[i] = lpdict_g[i];
+    for (int i = tid; i < a.ntail; i += nt) { l_tlp[i] = a.tlp[i]; l_tsrc[i] = a.tsrc[i]; }
+    const int64_t s = (int64_t)c * a.B;
+    const int64_t e = (s + a.B < a.T) ? s + a.B : a.T;
+    const int64_t w = (s - a.H > 0) ? s - a.H : 0;
+    const double c0 = a.c0, den = a.den, rden = a.rden;
+    double *warm = a.warmv + (int64_t)c * S;
+    double *gcol = a.gbuf + (int64_t)c * 2 * S;
+    double mean_r[SPT];
+    unsigned ci[SPT];  // source | dictionary index << 15 | single-source & in-range flag << 23
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+        const int jj = tid + i * nt;
+        const int j = jj < S ? jj : S - 1;
+        mean_r[i] = a.mean[j];
+        const unsigned wr = (jj < S && (a.tinfo[j] & 255) == 0) ? 1u : 0u;
+        ci[i] = (unsigned)a.src0[j] | ((unsigned)lpidx[j] << 15) | (wr << 23);
+    }
+    {
+        const double y0 = a.y[w];
+        for (int j = tid; j < S; j += nt)
+            gcol[j] = (w == 0 && j == 0) ? 0.0 : funcl_m(y0, a.mean[j], c0, den, rden);
+    }
+    int par = 0;
+    double ynext = a.y[w + 1 < e ? w + 1 : w];
+    __syncthreads();
+    for (int64_t t = w + 1; t < e; t++) {
+        const double yt = ynext;
+        ynext = a.y[t + 1 < e ? t + 1 : t];
+        __threadfence_block();
+        __syncthreads();
+        par ^= 1;
+        const double *prev = gcol + (par ^ 1) * S;
+        double *cur = gcol + par * S;
+        if (t == s && s > 0)
+            for (int j = tid; j < S; j += nt) warm[j] = prev[j];
+        const bool own = t >= s;
+        // prev and cur are different arrays: batches of 7 loads in flight are enough
+#pragma unroll
+        for (int i0 = 0; i0 < SPT; i0 += 7) {
+            double pv[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) pv[i] = prev[ci[i0 + i] & 0x7fffu];
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                const unsigned w_ = ci[i0 + i];
+                const double v = (pv[i] + lpd[(w_ >> 15) & 255u]) + funcl_m(yt, mean_r[i0 + i], c0, den, rden);
+                if (w_ >> 23) cur[tid + (i0 + i) * nt] = v;
+            }
+        }
+        for (int m = tid; m < a.nms; m += nt) {
+            const MsRec r = a.ms[m];
+            const double tt = prev[r.s0] + r.lp0;
+            const bool up = tt > -INFINITY;
+            double best = up ? tt : -INFINITY;
+            int arg = up ? r.s0 + 1 : 1;
+            block_tail(prev, r.ti, l_tsrc, l_tlp, best, arg);
+            cur[r.j] = best + funcl_m(yt, r.mean, c0, den, rden);
+            if (own) a.T2c[(int64_t)a.nms * t + m] = (int16_t)arg;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int j = tid; j < S; j += nt) a.endv[(int64_t)c * S + j] = gcol[par * S + j];
 }
 
 // Boundary certificate: spread over the states of (warm column of block c) - (end column of block
@@ -666,6 +753,9 @@ int blocked_set_model(GenericDev *g, const HostModel &m)
     std::vector<double> lp0(S, -INFINITY), tlp;
     std::vector<int32_t> src0(S, 0), tinfo(S, 0), tsrc, bt(S, 1);
     std::vector<MsRec> ms;
+    std::vector<double> dict;
+    std::vector<uint8_t> didx(S, 0);
+    bool dict_ok = true;
     for (int64_t j = 0; j < S; j++) {
         const int b = m.in_ptr[j], e = m.in_ptr[j + 1];
         if (e > b) { lp0[j] = m.in_lp[b]; src0[j] = m.in_src[b]; }
@@ -675,11 +765,19 @@ int blocked_set_model(GenericDev *g, const HostModel &m)
         tinfo[j] = (int32_t)((tsrc.size() << 8) | (unsigned)nt);
         for (int q = b + 1; q < e; q++) { tsrc.push_back(m.in_src[q]); tlp.push_back(m.in_lp[q]); }
         bt[j] = src0[j] + 1;
+        if (dict_ok) {  // dictionary of first-transition log-probabilities (bit patterns)
+            size_t q = 0;
+            while (q < dict.size() && memcmp(&dict[q], &lp0[j], 8) != 0) q++;
+            if (q == dict.size()) { if (dict.size() < 256) dict.push_back(lp0[j]); else dict_ok = false; }
+            if (dict_ok) didx[j] = (uint8_t)q;
+        }
         if (nt > 0) {
             bt[j] = -(int32_t)ms.size();
             ms.push_back(MsRec{lp0[j], m.mean[j], (int32_t)j, src0[j], tinfo[j], 0});
         }
     }
+    g->ndict = dict_ok ? (int)dict.size() : 0;
+    dict.resize(256, 0.0);
     if (g->ntail < 0) {  // first call: allocate
         g->ntail = (int)tsrc.size();
         int rc;
@@ -688,13 +786,16 @@ int blocked_set_model(GenericDev *g, const HostModel &m)
             (rc = dalloc(&g->d_tsrc, tsrc.size(), &g->bytes)) ||
             (rc = dalloc(&g->d_tlp, tlp.size(), &g->bytes)) ||
             (rc = dalloc((MsRec **)&g->d_ms, ms.size(), &g->bytes)) ||
-            (rc = dalloc(&g->d_bt, S, &g->bytes)))
+            (rc = dalloc(&g->d_bt, S, &g->bytes)) || (rc = dalloc(&g->d_lpdict, 256, &g->bytes)) ||
+            (rc = dalloc(&g->d_lpidx, S, &g->bytes)))
             return rc;
         g->nms = (int)ms.size();
     }
     HS_CHECK((int)tsrc.size() == g->ntail && (int)ms.size() == g->nms, HMMSORT_EINVAL,
              "set_model: transition structure changed");
     HS_HIP(hipMemcpy(g->d_bt, bt.data(), S * sizeof(int32_t), hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(g->d_lpdict, dict.data(), 256 * sizeof(double), hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(g->d_lpidx, didx.data(), S, hipMemcpyHostToDevice));
     if (!ms.empty())
         HS_HIP(hipMemcpy(g->d_ms, ms.data(), ms.size() * sizeof(MsRec), hipMemcpyHostToDevice));
     HS_HIP(hipMemcpy(g->d_lp0, lp0.data(), S * sizeof(double), hipMemcpyHostToDevice));
@@ -738,7 +839,7 @@ int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t
 void blocked_destroy(GenericDev *g)
 {
     void *ptrs[] = {g->d_lp0, g->d_src0, g->d_tinfo, g->d_tsrc, g->d_tlp, g->d_endv, g->d_warmv,
-                    g->d_fmap, g->d_merged, g->d_endstate, g->d_llpart, g->d_bdiag, g->d_blkbuf, g->d_ms, g->d_bt, g->d_fconst};
+                    g->d_fmap, g->d_merged, g->d_endstate, g->d_llpart, g->d_bdiag, g->d_blkbuf, g->d_ms, g->d_bt, g->d_fconst, g->d_lpdict, g->d_lpidx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -806,6 +907,20 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
         else if (spt1 <= 10) rc = go(gen_vit_block1<10>);
         else if (spt1 <= 11) rc = go(gen_vit_block1<11>);
         else rc = go(gen_vit_block1<12>);
+    } else if (gcol && g->ndict > 0 && S <= 21 * 1024 && (size_t)256 * 8 + (size_t)g->ntail * 12 + 8 <= 150 * 1024) {
+        const size_t ldsg = (size_t)256 * 8 + (size_t)g->ntail * 12 + 8;
+        const int sptg = (int)((S + 1023) / 1024);
+        auto go = [&](auto kern) -> int {
+            if (ldsg > 64 * 1024)
+                HS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)ldsg));
+            hipLaunchKernelGGL(kern, dim3((unsigned)g->nblk), dim3(1024), ldsg, st, a, g->d_lpdict, g->ndict,
+                               g->d_lpidx);
+            HS_HIP(hipGetLastError());
+            return HMMSORT_OK;
+        };
+        if (sptg <= 14) rc = go(gen_vit_blockG<14>);
+        else rc = go(gen_vit_blockG<21>);
     } else
     if (spt == 1 && nbthr) rc = launch_block_sweep<1, true, false, true>(g, a, threads, lds, st);
     else if (spt == 2 && nbthr) rc = launch_block_sweep<2, true, false, true>(g, a, threads, lds, st);

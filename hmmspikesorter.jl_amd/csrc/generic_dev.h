@@ -25,6 +25,9 @@ struct GenericDev {
     double *d_llpart = nullptr, *d_blkbuf = nullptr;
     int32_t *d_src0 = nullptr, *d_tinfo = nullptr, *d_tsrc = nullptr, *d_bt = nullptr;
     void *d_ms = nullptr;  // MsRec[nms]
+    double *d_lpdict = nullptr;  // <= 256 distinct first-transition log-probabilities
+    uint8_t *d_lpidx = nullptr;  // [S] index into it
+    int ndict = 0;               // 0: more than 256 distinct values, dictionary unusable
     int nms = 0;
     int16_t *d_fmap = nullptr, *d_endstate = nullptr, *d_fconst = nullptr;
     int64_t *d_merged = nullptr;
