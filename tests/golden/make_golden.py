@@ -51,3 +51,5 @@ if __name__ == "__main__":
     case("n2k5_noov", 2, 5, 200, False, 12, [0.02, 0.01], two, True)
     case("n3k60", 3, 60, 2000, False, 13, [0.003, 0.001, 0.002], two + [(2.5, 0.6, 0.25)], False)
     case("n2k20", 2, 20, 1500, False, 14, [0.01, 0.004], two, False)
+    # long enough for the time-parallel blocked engine (overlap model, T >= 4096)
+    case("n2k16_ov", 2, 16, 6000, True, 15, [0.01, 0.006], two, False)

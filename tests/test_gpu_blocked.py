@@ -175,3 +175,16 @@ def test_arbitrary_lists(O, H):
     assert p.info()["engine"] == H.ENGINE_BLOCKED
     p.close()
     _check(O, H, y, sm, mu, 0.7)
+
+
+def test_golden_overlap_fixture_through_blocked_engine(H):
+    # committed vectors (tests/golden/n2k16_ov.npz, made by make_golden.py from the oracle):
+    # no oracle call here -- the decode is compared with the stored path and ll
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "n2k16_ov.npz"))
+    N, K = int(g["N"]), int(g["K"])
+    sm = H.StateMatrix.create(N, K, np.log(g["pp"]), True)
+    assert np.array_equal(sm.transitions["src"], g["src"]) and np.array_equal(sm.transitions["lp"], g["val"])
+    x, ll = H.viterbi(g["y"], sm, np.asfortranarray(g["temps"]), 0.3)
+    assert H.get_option("last_escalations") == 0
+    assert np.array_equal(x, g["x"]) and abs(ll - float(g["ll"])) <= LL_RTOL * abs(float(g["ll"]))
