@@ -57,9 +57,10 @@ def test_reference_viterbi_test_shape(O, H):
 
 # (3, 58): 9 919 states, one LDS column updated in place; (4, 40): 9 283 states, constants re-read
 # every sample; (4, 45): 11 837 states with more multi-source states; (4, 48): 13 443 states, columns
-# in global memory with the constants in registers
+# in global memory with the constants in registers; (4, 56): 18 371 states, columns in
+# global memory again (larger dictionary index range, more rows per thread)
 @pytest.mark.parametrize("N,K,T", [(3, 20, 30011), (2, 33, 4097), (4, 12, 25000), (3, 58, 9000),
-                                   (4, 40, 6000), (4, 45, 5000), (4, 48, 5000)])
+                                   (4, 40, 6000), (4, 45, 5000), (4, 48, 5000), (4, 56, 3000 + 4096)])
 def test_overlap_shapes(O, H, N, K, T):
     temps = _templates(H, K, N)
     pp = [0.01, 0.006, 0.008, 0.005][:N]
