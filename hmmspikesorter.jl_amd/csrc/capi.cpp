@@ -579,6 +579,53 @@ int hmmsort_unroll_mlseq(const int16_t *mlseq, int64_t T, const int16_t *states,
     return HMMSORT_OK;
 }
 
+// extract_spiketimes on a path that already lives in device memory
+static int extract_from_device(const int16_t *d_x, int64_t T, const int16_t *states, int64_t N,
+                               int64_t S, const double *mu, int64_t K, int64_t *times_out,
+                               int64_t cap, int64_t *counts_out, hipStream_t st)
+{
+    // indmin(mu[:,i]): first minimum (extraction.jl:18); match table per state
+    std::vector<uint32_t> match(S, 0u);
+    for (int64_t i = 0; i < N; i++) {
+        int64_t q = 0;
+        for (int64_t k = 1; k < K; k++)
+            if (mu[k + K * i] < mu[q + K * i]) q = k;
+        for (int64_t j = 0; j < S; j++)
+            if (states[i + N * j] == q + 1) match[j] |= (1u << i);
+    }
+    const int64_t nb = (T + kSpikeChunkHost - 1) / kSpikeChunkHost;
+    DevBuf dm, dcnt, doff, dt;
+    int rc;
+    if ((rc = dm.alloc(S * sizeof(uint32_t))) || (rc = dcnt.alloc(nb * N * sizeof(int64_t))) ||
+        (rc = doff.alloc(nb * N * sizeof(int64_t))) ||
+        (rc = dt.alloc(std::max<int64_t>(1, N * cap) * sizeof(int64_t))))
+        return rc;
+    HS_HIP(hipMemcpyAsync(dm.p, match.data(), S * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if ((rc = dev_spike_compact(d_x, T, dm.as<uint32_t>(), (int)N, (int)S, 0, dcnt.as<int64_t>(), nullptr,
+                                nullptr, cap, st)))
+        return rc;
+    std::vector<int64_t> cnt(nb * N), off(nb * N);
+    HS_HIP(hipMemcpyAsync(cnt.data(), dcnt.p, cnt.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HS_HIP(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < N; i++) {
+        int64_t acc = 0;
+        for (int64_t b = 0; b < nb; b++) { off[b * N + i] = acc; acc += cnt[b * N + i]; }
+        counts_out[i] = acc;
+    }
+    if (cap == 0) return HMMSORT_OK;
+    HS_HIP(hipMemcpyAsync(doff.p, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    if ((rc = dev_spike_compact(d_x, T, dm.as<uint32_t>(), (int)N, (int)S, 1, dcnt.as<int64_t>(),
+                                doff.as<int64_t>(), dt.as<int64_t>(), cap, st)))
+        return rc;
+    for (int64_t i = 0; i < N; i++) {
+        const int64_t n = std::min(counts_out[i], cap);
+        HS_HIP(hipMemcpyAsync(times_out + i * cap, dt.as<int64_t>() + i * cap, n * sizeof(int64_t),
+                              hipMemcpyDeviceToHost, st));
+    }
+    HS_HIP(hipStreamSynchronize(st));
+    return HMMSORT_OK;
+}
+
 int hmmsort_extract_spiketimes(const int16_t *mlseq, int64_t T, const int16_t *states, int64_t N,
                                int64_t S, const double *mu, int64_t K, int64_t *times_out,
                                int64_t cap, int64_t *counts_out)
@@ -591,45 +638,22 @@ int hmmsort_extract_spiketimes(const int16_t *mlseq, int64_t T, const int16_t *s
     if (T == 0) return HMMSORT_OK;
     int rc = need_device();
     if (rc) return rc;
-    // indmin(mu[:,i]): first minimum (extraction.jl:18); match table per state
-    std::vector<uint32_t> match(S, 0u);
-    for (int64_t i = 0; i < N; i++) {
-        int64_t q = 0;
-        for (int64_t k = 1; k < K; k++)
-            if (mu[k + K * i] < mu[q + K * i]) q = k;
-        for (int64_t j = 0; j < S; j++)
-            if (states[i + N * j] == q + 1) match[j] |= (1u << i);
-    }
-    const int64_t nb = (T + kSpikeChunkHost - 1) / kSpikeChunkHost;
-    DevBuf dx, dm, dcnt, doff, dt;
-    if ((rc = dx.alloc(T * sizeof(int16_t))) || (rc = dm.alloc(S * sizeof(uint32_t))) ||
-        (rc = dcnt.alloc(nb * N * sizeof(int64_t))) || (rc = doff.alloc(nb * N * sizeof(int64_t))) ||
-        (rc = dt.alloc(std::max<int64_t>(1, N * cap) * sizeof(int64_t))))
-        return rc;
+    DevBuf dx;
+    if ((rc = dx.alloc(T * sizeof(int16_t)))) return rc;
     HS_HIP(hipMemcpy(dx.p, mlseq, T * sizeof(int16_t), hipMemcpyHostToDevice));
-    HS_HIP(hipMemcpy(dm.p, match.data(), S * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if ((rc = dev_spike_compact(dx.as<int16_t>(), T, dm.as<uint32_t>(), (int)N, (int)S, 0,
-                                dcnt.as<int64_t>(), nullptr, nullptr, cap, nullptr)))
-        return rc;
-    std::vector<int64_t> cnt(nb * N), off(nb * N);
-    HS_HIP(hipMemcpy(cnt.data(), dcnt.p, cnt.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < N; i++) {
-        int64_t acc = 0;
-        for (int64_t b = 0; b < nb; b++) { off[b * N + i] = acc; acc += cnt[b * N + i]; }
-        counts_out[i] = acc;
-    }
-    if (cap == 0) return HMMSORT_OK;
-    HS_HIP(hipMemcpy(doff.p, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    if ((rc = dev_spike_compact(dx.as<int16_t>(), T, dm.as<uint32_t>(), (int)N, (int)S, 1,
-                                dcnt.as<int64_t>(), doff.as<int64_t>(), dt.as<int64_t>(), cap, nullptr)))
-        return rc;
-    HS_HIP(hipDeviceSynchronize());
-    for (int64_t i = 0; i < N; i++) {
-        const int64_t n = std::min(counts_out[i], cap);
-        HS_HIP(hipMemcpy(times_out + i * cap, dt.as<int64_t>() + i * cap, n * sizeof(int64_t),
-                         hipMemcpyDeviceToHost));
-    }
-    return HMMSORT_OK;
+    return extract_from_device(dx.as<int16_t>(), T, states, N, S, mu, K, times_out, cap, counts_out, nullptr);
+}
+
+int hmmsort_plan_extract_spiketimes(hmmsort_plan *p, const int16_t *d_x, int64_t *times_out, int64_t cap,
+                                    int64_t *counts_out, void *stream)
+{
+    HS_CHECK(p && d_x && counts_out && (cap == 0 || times_out) && cap >= 0, HMMSORT_EINVAL,
+             "plan_extract_spiketimes: bad argument");
+    const HostModel &m = p->model;
+    HS_CHECK(m.N <= 32, HMMSORT_EINVAL, "plan_extract_spiketimes: more than 32 neurons");
+    for (int64_t i = 0; i < m.N; i++) counts_out[i] = 0;
+    return extract_from_device(d_x, p->T, m.states.data(), m.N, m.S, m.mu.data(), m.K, times_out, cap,
+                               counts_out, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -96,6 +96,19 @@ class Plan:
             out[i] = struct.unpack("<d", struct.pack("<q", out[i]))[0]
         return out
 
+    def extract_spiketimes(self, d_x, stream=0):
+        """extract_spiketimes (extraction.jl:15-24) from the decoded path in device memory:
+        list of 1-based sample-index arrays, one per neuron (only the spike times leave the GPU)."""
+        counts = np.zeros(self.N, dtype=np.int64)
+        check(lib().hmmsort_plan_extract_spiketimes(self._h, _dptr(d_x), None, 0, ptr(counts),
+                                                    C.c_void_p(stream)))
+        cap = int(counts.max()) if self.N else 0
+        times = np.zeros((self.N, max(cap, 1)), dtype=np.int64)
+        if cap:
+            check(lib().hmmsort_plan_extract_spiketimes(self._h, _dptr(d_x), ptr(times), cap,
+                                                        ptr(counts), C.c_void_p(stream)))
+        return [times[i, :counts[i]].copy() for i in range(self.N)]
+
     def profile(self, enable=True):
         check(lib().hmmsort_plan_profile(self._h, int(bool(enable))))
 

@@ -199,6 +199,13 @@ int hmmsort_plan_mstep(hmmsort_plan *plan, const double *d_stats, double *d_out,
  *           [3..6]. */
 int hmmsort_plan_diagnostics(hmmsort_plan *plan, void *stream, int64_t diag[8]);
 
+/* extract_spiketimes (extraction.jl:15-24) on a decoded path that is still in device memory
+ * (the x written by hmmsort_plan_viterbi): only the spike times cross PCIe, not the 2 bytes per
+ * sample of the path.  Model (states, mu) = the plan's current one.  Host outputs as in
+ * hmmsort_extract_spiketimes; synchronises the stream. */
+int hmmsort_plan_extract_spiketimes(hmmsort_plan *plan, const int16_t *d_x, int64_t *times_out,
+                                    int64_t cap, int64_t *counts_out, void *stream);
+
 /* Per-kernel timing of the ring engine with HIP events recorded on the caller's stream (used by
  * bench.py for the roofline line).  hmmsort_plan_profile(plan, 1) switches bracketing on;
  * hmmsort_plan_profile_read synchronises the stream and returns, per kernel name, the total

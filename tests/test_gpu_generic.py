@@ -179,6 +179,17 @@ def test_extract_spiketimes(O, H):
         ref = O.extract_spiketimes(model.ml_seq, to_oracle_sm(O, sm), temps)
         assert len(got) == 2 and all(np.array_equal(g, r) for g, r in zip(got, ref))
         assert all(len(g) > 10 and np.all(np.diff(g) > 0) for g in got)
+        # the same from a path that never leaves the device (hmmsort_plan_extract_spiketimes)
+        import torch
+        from hmmsort_amd import device
+        p = device.Plan(T, sm, temps, 0.3)
+        dy = torch.from_numpy(y).cuda()
+        dx = torch.zeros(T, dtype=torch.int16, device="cuda")
+        dll = torch.zeros(1, dtype=torch.float64, device="cuda")
+        p.viterbi(dy, dx, dll)
+        dev = p.extract_spiketimes(dx)
+        p.close()
+        assert all(np.array_equal(g, r) for g, r in zip(dev, ref))
 
 
 def test_large_overlap_model_uses_global_state_vectors(O, H):
