@@ -65,6 +65,8 @@ SIGNATURES = {
     "hmmsort_plan_mstep": (_int, [_vp, _vp, _vp, _vp]),
     "hmmsort_plan_diagnostics": (_int, [_vp, _vp, _pi64]),
     "hmmsort_plan_extract_spiketimes": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "hmmsort_plan_reconstruct": (_int, [_vp, _vp, _vp, _vp]),
+    "hmmsort_plan_unroll_mlseq": (_int, [_vp, _vp, _vp, _vp]),
     "hmmsort_plan_profile": (_int, [_vp, _int]),
     "hmmsort_plan_profile_read": (_int, [_vp, _vp, C.c_char_p, _i64, C.POINTER(_f64), _pi64, _i64,
                                          _pi64]),

@@ -644,6 +644,38 @@ int hmmsort_extract_spiketimes(const int16_t *mlseq, int64_t T, const int16_t *s
     return extract_from_device(dx.as<int16_t>(), T, states, N, S, mu, K, times_out, cap, counts_out, nullptr);
 }
 
+// reconstruct_signal / unroll_mlseq on a path in device memory, results left in device memory
+static int plan_path_op(hmmsort_plan *p, const int16_t *d_x, double *d_y_out, int16_t *d_unrolled,
+                        hipStream_t st)
+{
+    const HostModel &m = p->model;
+    DevBuf dst, dmu;
+    int rc;
+    if ((rc = dst.alloc(m.N * m.S * sizeof(int16_t))) || (rc = dmu.alloc(m.K * m.N * sizeof(double))))
+        return rc;
+    HS_HIP(hipMemcpyAsync(dst.p, m.states.data(), m.N * m.S * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    HS_HIP(hipMemcpyAsync(dmu.p, m.mu.data(), m.K * m.N * sizeof(double), hipMemcpyHostToDevice, st));
+    if (d_y_out)
+        rc = dev_reconstruct(d_x, p->T, dst.as<int16_t>(), m.N, m.S, dmu.as<double>(), m.K, d_y_out, st);
+    else
+        rc = dev_unroll(d_x, p->T, dst.as<int16_t>(), m.N, m.S, d_unrolled, st);
+    if (rc) return rc;
+    HS_HIP(hipStreamSynchronize(st));  // the temporaries die with this frame
+    return HMMSORT_OK;
+}
+
+int hmmsort_plan_reconstruct(hmmsort_plan *p, const int16_t *d_x, double *d_y_out, void *stream)
+{
+    HS_CHECK(p && d_x && d_y_out, HMMSORT_EINVAL, "plan_reconstruct: null argument");
+    return plan_path_op(p, d_x, d_y_out, nullptr, (hipStream_t)stream);
+}
+
+int hmmsort_plan_unroll_mlseq(hmmsort_plan *p, const int16_t *d_x, int16_t *d_out, void *stream)
+{
+    HS_CHECK(p && d_x && d_out, HMMSORT_EINVAL, "plan_unroll_mlseq: null argument");
+    return plan_path_op(p, d_x, nullptr, d_out, (hipStream_t)stream);
+}
+
 int hmmsort_plan_extract_spiketimes(hmmsort_plan *p, const int16_t *d_x, int64_t *times_out, int64_t cap,
                                     int64_t *counts_out, void *stream)
 {

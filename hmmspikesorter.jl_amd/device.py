@@ -96,6 +96,14 @@ class Plan:
             out[i] = struct.unpack("<d", struct.pack("<q", out[i]))[0]
         return out
 
+    def reconstruct(self, d_x, d_y_out, stream=0):
+        """reconstruct_signal of a decoded path, device to device (T doubles)"""
+        check(lib().hmmsort_plan_reconstruct(self._h, _dptr(d_x), _dptr(d_y_out), C.c_void_p(stream)))
+
+    def unroll_mlseq(self, d_x, d_out, stream=0):
+        """unroll_mlseq of a decoded path, device to device (N x T int16, column-major)"""
+        check(lib().hmmsort_plan_unroll_mlseq(self._h, _dptr(d_x), _dptr(d_out), C.c_void_p(stream)))
+
     def extract_spiketimes(self, d_x, stream=0):
         """extract_spiketimes (extraction.jl:15-24) from the decoded path in device memory:
         list of 1-based sample-index arrays, one per neuron (only the spike times leave the GPU)."""

@@ -199,6 +199,13 @@ int hmmsort_plan_mstep(hmmsort_plan *plan, const double *d_stats, double *d_out,
  *           [3..6]. */
 int hmmsort_plan_diagnostics(hmmsort_plan *plan, void *stream, int64_t diag[8]);
 
+/* reconstruct_signal (reconstruction.jl:1-10) and unroll_mlseq (extraction.jl:4-13) of a decoded
+ * path in device memory into device buffers (T doubles / N x T Int16, column-major); the model
+ * is the plan's current one.  Out-of-range state ids give NaN / 0 as in the host-buffer kernels'
+ * device code; synchronise the stream. */
+int hmmsort_plan_reconstruct(hmmsort_plan *plan, const int16_t *d_x, double *d_y_out, void *stream);
+int hmmsort_plan_unroll_mlseq(hmmsort_plan *plan, const int16_t *d_x, int16_t *d_out, void *stream);
+
 /* extract_spiketimes (extraction.jl:15-24) on a decoded path that is still in device memory
  * (the x written by hmmsort_plan_viterbi): only the spike times cross PCIe, not the 2 bytes per
  * sample of the path.  Model (states, mu) = the plan's current one.  Host outputs as in

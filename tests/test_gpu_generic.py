@@ -188,8 +188,16 @@ def test_extract_spiketimes(O, H):
         dll = torch.zeros(1, dtype=torch.float64, device="cuda")
         p.viterbi(dy, dx, dll)
         dev = p.extract_spiketimes(dx)
+        dY = torch.zeros(T, dtype=torch.float64, device="cuda")
+        dU = torch.zeros(T * 2, dtype=torch.int16, device="cuda")
+        p.reconstruct(dx, dY)
+        p.unroll_mlseq(dx, dU)
         p.close()
         assert all(np.array_equal(g, r) for g, r in zip(dev, ref))
+        xh = dx.cpu().numpy()
+        assert np.array_equal(dY.cpu().numpy(), O.reconstruct_signal(xh, to_oracle_sm(O, sm), temps))
+        assert np.array_equal(dU.cpu().numpy().reshape((2, T), order="F"),
+                              O.unroll_mlseq(xh, to_oracle_sm(O, sm)))
 
 
 def test_large_overlap_model_uses_global_state_vectors(O, H):
