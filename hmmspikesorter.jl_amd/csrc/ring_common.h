@@ -74,7 +74,8 @@ struct RingDev {
     bool prof_on = false;
     const double *bound_y = nullptr;  // signal whose yT/Rf are current (hmmsort_plan_bind)
     hipStream_t side = nullptr;        // internal stream: decode post-processing beside the E-step's
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_post = nullptr, ev_chk = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_post = nullptr, ev_chk = nullptr,
+               ev_edges = nullptr;
     std::vector<ProfEntry> prof;
     int64_t S = 0, K = 0;
     double sigma = 0, lsig = 0, A = 0, den = 0;

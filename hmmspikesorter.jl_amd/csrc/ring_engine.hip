@@ -182,7 +182,8 @@ int ring_create(RingDev **out, const HostModel &m, int64_t T, int64_t block_req,
         hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&r->ev_post, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&r->ev_chk, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&r->ev_chk, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_edges, hipEventDisableTiming) != hipSuccess) {
         set_error("ring engine: could not create the internal stream/events");
         ring_destroy(r);
         return HMMSORT_EHIP;
@@ -203,6 +204,7 @@ void ring_destroy(RingDev *r)
     if (r->ev_join) (void)hipEventDestroy(r->ev_join);
     if (r->ev_post) (void)hipEventDestroy(r->ev_post);
     if (r->ev_chk) (void)hipEventDestroy(r->ev_chk);
+    if (r->ev_edges) (void)hipEventDestroy(r->ev_edges);
     if (r->side) (void)hipStreamDestroy(r->side);
     delete r;
 }

@@ -837,6 +837,11 @@ int ring_estep_post(RingDev *r, const double *d_y, double *d_stats, hipStream_t 
         // stream beside the statistics kernels and is joined at the end of this function
         HS_HIP(hipEventRecord(r->ev_post, st));
         HS_HIP(hipStreamWaitEvent(r->side, r->ev_post, 0));
+        // the edge terms (virtual onsets, end-of-data tails, pp: one thread per ring state, latency
+        // bound) need the posteriors only as well: first on the side stream, then the certificate
+        { PROF(r, "k_stats_edges", r->side); hipLaunchKernelGGL(k_stats_edges, dim3((NL + 63) / 64), dim3(64), 0, r->side, g, d_y, r->P, r->Q, r->A0, r->B0,
+                           r->Zc, r->rhoT, r->extra, r->pp); }
+        HS_HIP(hipEventRecord(r->ev_edges, r->side));
         { PROF(r, "k_fb_check", r->side); hipLaunchKernelGGL((k_fb_check<NN>), dim3(colgroups), dim3(64 * kChkParts), 0, r->side, g, 1e-9, r->P, r->Q,
                            r->A0, r->B0, r->B0h, r->Zc, r->rhoT, r->diag); }
         HS_HIP(hipEventRecord(r->ev_chk, r->side));
@@ -895,8 +900,7 @@ int ring_estep_post(RingDev *r, const double *d_y, double *d_stats, hipStream_t 
         return HMMSORT_OK;
     });
     if (rc) return rc;
-    { PROF(r, "k_stats_edges", st); hipLaunchKernelGGL(k_stats_edges, dim3((NL + 63) / 64), dim3(64), 0, st, g, d_y, r->P, r->Q, r->A0, r->B0,
-                       r->Zc, r->rhoT, r->extra, r->pp); }
+    HS_HIP(hipStreamWaitEvent(st, r->ev_edges, 0));
     const int total = 3 * NL + N + 4;
     { PROF(r, "k_stats_final", st); hipLaunchKernelGGL(k_stats_final, dim3(total), dim3(64), 0, st, N, L, colgroups,
                        colgroups * ((g.B + kPostRows - 1) / kPostRows), r->partA, r->partS, r->extra, d_stats); }
