@@ -216,7 +216,7 @@ int ring_mstep_launch(RingDev *r, const double *d_stats, double *d_out, hipStrea
 int ring_launch_transpose_in(RingDev *r, const double *d_y, hipStream_t st);
 int ring_launch_prepass(RingDev *r, hipStream_t st);
 int ring_launch_virtual(RingDev *r, const double *d_y, double *dst_planes, int64_t plane_stride,
-                        hipStream_t st);
+                        hipStream_t st, double *dst_planes2 = nullptr);
 int ring_bind(RingDev *r, const double *d_y, hipStream_t st);
 int ring_prepare(RingDev *r, const double *d_y, hipStream_t st);
 int ring_profile_enable(RingDev *r, int on);

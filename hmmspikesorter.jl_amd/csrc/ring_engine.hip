@@ -360,7 +360,7 @@ int ring_launch_prepass(RingDev *r, hipStream_t st)
 // ------------------------------------------------------------------------------------------
 __global__ void k_virtual(RingGeom g, const double *__restrict__ y, const double *__restrict__ mean,
                           const double *__restrict__ cint, double den, double *__restrict__ dst,
-                          int64_t plane_stride)
+                          double *__restrict__ dst2, int64_t plane_stride)
 {
     const int L = g.L, N = g.N;
     for (int i = threadIdx.x; i < N * L; i += blockDim.x) {
@@ -377,14 +377,15 @@ __global__ void k_virtual(RingGeom g, const double *__restrict__ y, const double
             v = (cint[a * (L + 1) + L] - cint[a * (L + 1) + (1 + j)]) - acc / den;
         }
         dst[(int64_t)a * plane_stride + (int64_t)(g.H - j) * g.ncol + 0] = v;
+        if (dst2) dst2[(int64_t)a * plane_stride + (int64_t)(g.H - j) * g.ncol + 0] = v;
     }
 }
 
 int ring_launch_virtual(RingDev *r, const double *d_y, double *dst, int64_t plane_stride,
-                        hipStream_t st)
+                        hipStream_t st, double *dst2)
 {
     { PROF(r, "k_virtual", st); hipLaunchKernelGGL(k_virtual, dim3(1), dim3(256), 0, st, r->g, d_y, r->d_mean, r->d_cint, r->den,
-                       dst, plane_stride); }
+                       dst, dst2, plane_stride); }
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }

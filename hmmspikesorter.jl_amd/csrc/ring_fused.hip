@@ -40,8 +40,7 @@ int ring_decode_estep_launch(RingDev *r, const double *d_y, int16_t *d_x, double
     HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
     if ((rc = ring_prepare(r, d_y, st))) return rc;
     const int64_t planeP = (int64_t)(g.H + g.B) * g.ncol;
-    if ((rc = ring_launch_virtual(r, d_y, r->Pv, planeP, st))) return rc;
-    if ((rc = ring_launch_virtual(r, d_y, r->P, planeP, st))) return rc;
+    if ((rc = ring_launch_virtual(r, d_y, r->Pv, planeP, st, r->P))) return rc;  // both delay lines
     rc = dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
         JParams<N> jp = make_jparams<N>(r);
