@@ -359,8 +359,8 @@ int ring_launch_prepass(RingDev *r, hipStream_t st)
 // is the "no such onset" marker -Inf.
 // ------------------------------------------------------------------------------------------
 __global__ void k_virtual(RingGeom g, const double *__restrict__ y, const double *__restrict__ mean,
-                          const double *__restrict__ cint, double den, double *__restrict__ dst,
-                          double *__restrict__ dst2, int64_t plane_stride)
+                          const double *__restrict__ cint, double den, double A,
+                          double *__restrict__ dst, double *__restrict__ dst2, int64_t plane_stride)
 {
     const int L = g.L, N = g.N;
     for (int i = threadIdx.x; i < N * L; i += blockDim.x) {
@@ -368,6 +368,15 @@ __global__ void k_virtual(RingGeom g, const double *__restrict__ y, const double
         double v;
         if (j == L) {
             v = -INFINITY;
+        } else if (j == L - 1) {
+            // A ring in its LAST phase at the first sample: one emission term.  Template tails are
+            // ~1e-16 (sin(3*pi)), so these N candidates tie to the last bit in the reference, whose
+            // first column is funcl = A - d*d/den (viterbi.jl:55-62) with the small term absorbed
+            // into A's rounding; with sigma < 0.4 (A > 0) one of them usually IS the decoded first
+            // state.  Round exactly like the reference, then take A out again, so that equal
+            // reference values stay equal here and the lowest ring wins the tie as it does there.
+            const double d = y[0] - mean[1 + a * L + (L - 1)];
+            v = (A - (d * d) / den) - A;
         } else {
             double acc = 0.0;
             for (int k = 1 + j; k <= L; k++) {
@@ -385,7 +394,7 @@ int ring_launch_virtual(RingDev *r, const double *d_y, double *dst, int64_t plan
                         hipStream_t st, double *dst2)
 {
     { PROF(r, "k_virtual", st); hipLaunchKernelGGL(k_virtual, dim3(1), dim3(256), 0, st, r->g, d_y, r->d_mean, r->d_cint, r->den,
-                       dst, dst2, plane_stride); }
+                       r->A, dst, dst2, plane_stride); }
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }

@@ -378,6 +378,48 @@ int ring_viterbi_launch(RingDev *r, const double *d_y, int16_t *d_x, double *d_l
     return ring_viterbi_post(r, d_y, d_x, d_ll, st);
 }
 
+// The first decoded state, exactly as the reference finds it: x[0] = psi_1(x[1]) and psi_1 only sees
+// the first trellis column, which is plain emission (viterbi.jl:55-63): T1[s,0] = funcl(y[0], mean_s),
+// T1[1,0] = 0.  Template tails are ~1e-16, so the "ring in its last phase at sample 0" candidates
+// differ by a few ulps only, and with sigma < 0.4 (funcl > 0 there) one of them usually wins: the
+// reference's choice then hangs on the rounding of T1 + lp in ITS frame, which the ring engine's
+// per-sample constant shift cannot reproduce.  Re-deciding this one sample with the reference's
+// own operations (strict '>', list order = ascending source) makes it exact.
+__global__ void k_first_state(RingGeom g, const double *__restrict__ y, const double *__restrict__ mean,
+                              const double *__restrict__ ctab, double A, double den,
+                              int16_t *__restrict__ x)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0 || g.T < 2) return;
+    const int N = g.N, L = g.L;
+    const double *c0 = ctab + 1, *cend = ctab + 1 + N, *cx = ctab + 1 + 2 * N, *cint = ctab + 1 + 2 * N + N * N;
+    const double y0 = y[0];
+    auto T1 = [&](int a, int k) {  // funcl, utils.jl:4, as the strict engine writes it
+        const double dd = y0 - mean[1 + a * L + (k - 1)];
+        return A - (dd * dd) / den;
+    };
+    double best = -INFINITY;
+    int arg = 1;
+    auto cand = [&](int state, double t1, double lp) {
+        const double tt = t1 + lp;
+        if (tt > best) { best = tt; arg = state; }
+    };
+    const int x1 = x[1];
+    if (x1 == 1) {
+        cand(1, 0.0, ctab[0]);
+        for (int a = 0; a < N; a++) cand(1 + a * L + L, T1(a, L), cend[a]);
+    } else {
+        const int b = (x1 - 2) / L, k = (x1 - 2) % L + 1;
+        if (k == 1) {
+            cand(1, 0.0, c0[b]);
+            for (int a = 0; a < N; a++)
+                if (a != b) cand(1 + a * L + L, T1(a, L), cx[a * N + b]);
+        } else {
+            cand(1 + b * L + (k - 1), T1(b, k - 1), cint[b * L + (k - 1)]);
+        }
+    }
+    x[0] = (int16_t)arg;
+}
+
 // everything after the chain sweep: final state, backtrace + stitch, boundary certificate, x, ll
 int ring_viterbi_post(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st)
 {
@@ -412,6 +454,8 @@ int ring_viterbi_post(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll,
     }
     { PROF(r, "k_transpose_x", st); hipLaunchKernelGGL(k_transpose_x, dim3(g.B / 64, g.ncol / 64), dim3(256), 0, st, r->xT, g.T,
                        g.B, g.ncol, d_x); }
+    { PROF(r, "k_first_state", st); hipLaunchKernelGGL(k_first_state, dim3(1), dim3(64), 0, st, g, d_y, r->d_mean, r->d_ctab,
+                       r->A, r->den, d_x); }
     { PROF(r, "k_ll_partial", st); hipLaunchKernelGGL(k_ll_partial, dim3(r->nparts), dim3(256), 0, st, g, d_y, d_x, r->d_mean,
                        r->d_ctab, r->A, r->den, r->part); }
     { PROF(r, "k_sum_partials", st); hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, r->part, r->nparts, d_ll); }

@@ -1,0 +1,68 @@
+"""Randomised parity sweep: decode (all engines AUTO picks) and one EM step against the CPU oracle
+over random model shapes, firing rates, noise levels and signal lengths.  Test infrastructure (it
+imports the oracle): python scripts/fuzz_gpu.py [n_cases] [seed]"""
+import sys, time
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import numpy as np
+import hmmsort_amd as H
+from oracle import oracle as O
+from conftest import to_oracle_sm
+
+
+
+def run(n_cases, seed, verbose=True):
+    """returns the list of failing case descriptions"""
+    rng = np.random.default_rng(seed)
+    failures = []
+    for case in range(n_cases):
+        ok, tag, msg = one_case(rng, case)
+        if not ok:
+            failures.append(tag + " -> " + msg)
+        if verbose:
+            print(tag, "->", msg, flush=True)
+    return failures
+
+
+def one_case(rng, case):
+    if True:
+        ov = bool(rng.integers(0, 2))
+        N = int(rng.integers(1, 5 if ov else 7))
+        K = int(rng.integers(2, 34 if ov else 70))
+        if ov and 1 + N * (K - 1) + N * (N - 1) // 2 * (K - 1) ** 2 > 6000:
+            K = max(2, int(np.sqrt(6000 / max(1, N * (N - 1) // 2))))
+        T = int(rng.integers(300, 40000))
+        sigma = float(rng.uniform(0.15, 0.6))
+        temps = np.asfortranarray(np.stack([H.create_spike_template(K, rng.uniform(1.5, 5), rng.uniform(0.2, 1.0),
+                                                                    rng.uniform(0.1, 0.4)) for _ in range(N)], 1))
+        pp = rng.uniform(5e-4, 8e-3, N) * min(1.0, 30.0 / K)
+        y = H.create_signal(T, sigma, pp, temps, seed=int(rng.integers(1, 1 << 30)))
+        sm = H.StateMatrix.create(N, K, np.log(pp), ov)
+        osm = to_oracle_sm(O, sm)
+        tag = "case %d: N=%d K=%d ov=%d S=%d T=%d sigma=%.2f" % (case, N, K, ov, sm.nstates, T, sigma)
+        try:
+            x, ll = H.viterbi(y, sm, temps, sigma)
+            esc = H.get_option("last_escalations")
+            xo, llo = O.viterbi(y, osm, temps, sigma)
+            ok = np.array_equal(x, xo) and abs(ll - llo) <= 1e-9 * abs(llo)
+            msg = "viterbi %s (esc %d)" % ("ok" if ok else "MISMATCH %d samples, ll rel %.2e" % ((x != xo).sum(), abs(ll - llo) / abs(llo)), esc)
+            if T * sm.nstates <= 4_000_000 and T >= 2:
+                mu = np.asfortranarray(temps * rng.uniform(0.8, 1.2, N)[None, :]); mu[0, :] = 0
+                sm_n, mu_n, sig_n = H.train_step(y, sm, mu.copy(order="F"), sigma * 1.2)
+                osm_n, omu, osig, olp, opp = O.train_step(y, osm, mu.copy(order="F"), sigma * 1.2)
+                fin = np.isfinite(omu)
+                ok2 = (np.array_equal(np.isfinite(mu_n), fin) and np.allclose(mu_n[fin], omu[fin], rtol=1e-6, atol=1e-9)
+                       and (abs(sig_n - osig) <= 1e-6 * osig or not np.isfinite(osig)))
+                msg += "; em_step %s" % ("ok" if ok2 else "MISMATCH max|dmu| %.2e dsig %.2e" % (np.nanmax(np.abs(mu_n - omu)), abs(sig_n - osig)))
+                ok = ok and ok2
+        except Exception as exc:  # noqa: BLE001
+            ok, msg = False, "EXCEPTION %r" % (exc,)
+    return ok, tag, msg
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    t00 = time.time()
+    bad = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+    print("%d cases, %d failures, %.0f s" % (n_cases, len(bad), time.time() - t00))
+    sys.exit(1 if bad else 0)
