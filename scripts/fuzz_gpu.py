@@ -24,22 +24,31 @@ def run(n_cases, seed, verbose=True):
     return failures
 
 
+STRESS = bool(int(__import__("os").environ.get("FUZZ_STRESS", "0")))  # bigger, busier models
+
+
 def one_case(rng, case):
     if True:
         ov = bool(rng.integers(0, 2))
-        N = int(rng.integers(1, 5 if ov else 7))
-        K = int(rng.integers(2, 34 if ov else 70))
-        if ov and 1 + N * (K - 1) + N * (N - 1) // 2 * (K - 1) ** 2 > 6000:
-            K = max(2, int(np.sqrt(6000 / max(1, N * (N - 1) // 2))))
-        T = int(rng.integers(300, 40000))
+        N = int(rng.integers(1, 5 if ov else (13 if STRESS else 7)))
+        K = int(rng.integers(2, 34 if ov else (200 if STRESS else 70)))
+        smax = 12000 if STRESS else 6000
+        if ov and 1 + N * (K - 1) + N * (N - 1) // 2 * (K - 1) ** 2 > smax:
+            K = max(2, int(np.sqrt(smax / max(1, N * (N - 1) // 2))))
+        T = int(rng.integers(300, 120000 if STRESS else 40000))
         sigma = float(rng.uniform(0.15, 0.6))
         temps = np.asfortranarray(np.stack([H.create_spike_template(K, rng.uniform(1.5, 5), rng.uniform(0.2, 1.0),
                                                                     rng.uniform(0.1, 0.4)) for _ in range(N)], 1))
-        pp = rng.uniform(5e-4, 8e-3, N) * min(1.0, 30.0 / K)
+        pp = rng.uniform(5e-4, 8e-3, N) * min(1.0, 30.0 / K) * (rng.choice([1.0, 3.0, 8.0]) if STRESS else 1.0)
         y = H.create_signal(T, sigma, pp, temps, seed=int(rng.integers(1, 1 << 30)))
         sm = H.StateMatrix.create(N, K, np.log(pp), ov)
         osm = to_oracle_sm(O, sm)
-        tag = "case %d: N=%d K=%d ov=%d S=%d T=%d sigma=%.2f" % (case, N, K, ov, sm.nstates, T, sigma)
+        blk = int(rng.choice([0, 0, 128, 192, 256, 512, 1024]))   # geometry requests: the engines clamp
+        hal = int(rng.choice([0, 0, 64, 128, 256, 512]))          # them; a short warm-up must escalate
+        H.set_option("block", blk)
+        H.set_option("halo", hal)
+        tag = "case %d: N=%d K=%d ov=%d S=%d T=%d sigma=%.2f block=%d halo=%d" % (case, N, K, ov, sm.nstates, T,
+                                                                              sigma, blk, hal)
         try:
             x, ll = H.viterbi(y, sm, temps, sigma)
             esc = H.get_option("last_escalations")
@@ -57,6 +66,8 @@ def one_case(rng, case):
                 ok = ok and ok2
         except Exception as exc:  # noqa: BLE001
             ok, msg = False, "EXCEPTION %r" % (exc,)
+        H.set_option("block", 0)
+        H.set_option("halo", 0)
     return ok, tag, msg
 
 

@@ -165,3 +165,18 @@ def test_unsupported_shapes_are_refused(O, H):
     x, ll = H.viterbi(np.zeros(1000), sm, np.zeros((30, 2)), 0.3)
     xo, llo = O.viterbi(np.zeros(1000), to_oracle_sm(O, sm), np.zeros((30, 2)), 0.3)
     assert np.array_equal(x, xo) and ll == llo
+
+
+def test_first_state_tie_regression(H):
+    # tests/golden/cases/first_state_tie.npz: 4 templates x 20 states, sigma 0.317; the decoded path
+    # starts in a ring's LAST phase and the four candidates' first-column scores differ by <= 6e-16
+    # (template tails ~1e-16).  Stored path = the oracle's.  Before k_first_state the ring engine
+    # reported state 39 instead of 58 for sample 0.
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cases", "first_state_tie.npz"))
+    sm = H.StateMatrix.create(int(g["N"]), int(g["K"]), np.log(g["pp"]), False)
+    H.set_option("engine", H.ENGINE_RING)
+    x, ll = H.viterbi(g["y"], sm, np.asfortranarray(g["temps"]), float(g["sigma"]))
+    H.set_option("engine", H.ENGINE_AUTO)
+    assert x[0] == 58 and np.array_equal(x, g["x"])
+    assert abs(ll - float(g["ll"])) <= 1e-9 * abs(float(g["ll"]))
