@@ -25,6 +25,7 @@ def run(n_cases, seed, verbose=True):
 
 
 STRESS = bool(int(__import__("os").environ.get("FUZZ_STRESS", "0")))  # bigger, busier models
+ENGINE = int(__import__("os").environ.get("FUZZ_ENGINE", "0"))        # 0 auto, 1 strict, 3 blocked (decode)
 
 
 def one_case(rng, case):
@@ -50,11 +51,29 @@ def one_case(rng, case):
         tag = "case %d: N=%d K=%d ov=%d S=%d T=%d sigma=%.2f block=%d halo=%d" % (case, N, K, ov, sm.nstates, T,
                                                                               sigma, blk, hal)
         try:
-            x, ll = H.viterbi(y, sm, temps, sigma)
+            H.set_option("engine", ENGINE)
+            try:
+                x, ll = H.viterbi(y, sm, temps, sigma)
+            finally:
+                H.set_option("engine", 0)
             esc = H.get_option("last_escalations")
             xo, llo = O.viterbi(y, osm, temps, sigma)
             ok = np.array_equal(x, xo) and abs(ll - llo) <= 1e-9 * abs(llo)
             msg = "viterbi %s (esc %d)" % ("ok" if ok else "MISMATCH %d samples, ll rel %.2e" % ((x != xo).sum(), abs(ll - llo) / abs(llo)), esc)
+            if T >= 3000 and rng.random() < 0.5:   # chunked decode with the stitch rule, fit.jl:11-42
+                cs = int(rng.integers(1000, T // 2))
+                rc, ml, llc = O.fit_chunked(y, osm, temps, sigma, cs)
+                try:
+                    mdl = H.fit(H.HMMSpikeTemplateModel(sm, temps, sigma), y, cs)
+                    ok3 = rc == 0 and np.array_equal(mdl.ml_seq, ml) and abs(mdl.ll - llc) <= 1e-9 * abs(llc)
+                    if ok3:
+                        sp = H.extract_spiketimes(mdl)
+                        spo = O.extract_spiketimes(ml, osm, temps)
+                        ok3 = all(np.array_equal(a_, b_) for a_, b_ in zip(sp, spo))
+                except IndexError:
+                    ok3 = rc == -3            # a chunk without a silent sample: both give up there
+                msg += "; fit(chunk=%d) %s" % (cs, "ok" if ok3 else "MISMATCH rc=%d" % rc)
+                ok = ok and ok3
             if T * sm.nstates <= 4_000_000 and T >= 2:
                 mu = np.asfortranarray(temps * rng.uniform(0.8, 1.2, N)[None, :]); mu[0, :] = 0
                 sm_n, mu_n, sig_n = H.train_step(y, sm, mu.copy(order="F"), sigma * 1.2)
