@@ -352,7 +352,8 @@ def fit(templates, X, chunksize=None):
                 plans[k] = Plan(k, lA, mu, sigma)
             plan = plans[k]
             plan.viterbi(dX.data_ptr() + (i - 1) * 8, dx, dll)
-            if plan.diagnostics()[0] != 0:      # a block boundary failed its warm-up check:
+            dg = plan.diagnostics()
+            if dg[0] != 0 or (plan.info()["engine"] == _lib.ENGINE_BLOCKED and dg[7] != 0):  # failed check / near-ties:
                 x, _ll = viterbi(X[i - 1:j], lA, mu, sigma)   # the escalating entry point
             else:
                 x, _ll = dx[:k].cpu().numpy(), float(dll.cpu()[0])

@@ -60,6 +60,7 @@ struct BlockArgs {
     double c0, den, rden;  // rden = RN(1/den)
     int16_t *T2c;         // [T][nms]
     double *endv, *warmv; // [nblk][S]
+    unsigned long long *gapmin;  // [nblk] bit pattern of the smallest non-zero candidate gap
     double *gbuf;         // [nblk][2S] when the columns do not fit LDS, else null
 };
 
@@ -85,17 +86,30 @@ __device__ __forceinline__ void lds_barrier()
 // the incoming transitions after the first one (multi-source states only): viterbi.jl:76-84
 // (a 4-wide batched variant of this loop was measured slower: it costs the registers that keep the
 // sweep at two workgroups per CU)
+constexpr double kGapCoarse = 1e-4;  // gaps above this are never near-ties (|trellis| < 1e10)
+// gmin collects the smallest NON-ZERO distance between a candidate and the running maximum: a block
+// works in its own additive frame, where two candidates a few ulps apart are told apart although
+// the reference, at the magnitude its trellis has by then, rounds them to a tie (and then takes the
+// first in list order).  Exactly equal candidates behave the same in every frame.
 template <typename PrevPtr, typename SrcPtr, typename LpPtr>
 __device__ __forceinline__ void block_tail(PrevPtr prev, int ti, SrcPtr tsrc, LpPtr tlp,
-                                           double &best, int &arg)
+                                           double &best, int &arg, double &gmin)
 {
     const int tn = ti & 255;
     int tp = ti >> 8;
     for (int k = 0; k < tn; k++, tp++) {
         const int sq = tsrc[tp];
         const double tt = prev[sq] + tlp[tp];
+        const double gd = fabs(tt - best);
+        if (gd < kGapCoarse && gd > 0.0) gmin = gd < gmin ? gd : gmin;  // rare
         if (tt > best) { best = tt; arg = sq + 1; }  // :80 strict, list order
     }
+}
+
+// gaps are published as they occur, and only when small (rare): no loop-carried register
+__device__ __forceinline__ void publish_gap(unsigned long long *gapmin, int c, double g)
+{
+    if (g < kGapCoarse) atomicMin(&gapmin[c], (unsigned long long)__double_as_longlong(g));
 }
 
 // One workgroup = one block.  With SPT > 0 every thread keeps the constants of its SPT states in
@@ -181,6 +195,7 @@ void gen_vit_block(BlockArgs a)
     }
     double ynext = a.y[w + 1 < e ? w + 1 : w];
     for (int64_t t = w + 1; t < e; t++) {
+        double gl = INFINITY;
         const double yt = ynext;
         ynext = a.y[t + 1 < e ? t + 1 : t];  // one sample ahead: its latency hides behind this column
         if (GCOL) { __threadfence_block(); __syncthreads(); }
@@ -217,8 +232,8 @@ void gen_vit_block(BlockArgs a)
                     double best = up ? tt : -INFINITY;
                     int arg = up ? s0 + 1 : 1;
                     const int ti = (m == tid) ? bti : a.tinfo[j];
-                    if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg);
-                    else block_tail(prev, ti, a.tsrc, a.tlp, best, arg);
+                    if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg, gl);
+                    else block_tail(prev, ti, a.tsrc, a.tlp, best, arg, gl);
                     const double v = best + funcl_m(yt, (m == tid) ? bmean : a.mean[j], c0, den, rden);
                     cur[j] = v;
                     if (own) psi[m] = (int16_t)arg;
@@ -232,11 +247,13 @@ void gen_vit_block(BlockArgs a)
                     double best = -INFINITY;
                     int arg = 1;
                     if (t0 > best) { best = t0; arg = s0 + 1; }
+                    { const double gd = fabs(t1 - best); if (gd < kGapCoarse && gd > 0.0) gl = gd < gl ? gd : gl; }
                     if (t1 > best) { best = t1; arg = s1 + 1; }
+                    { const double gd = fabs(t2 - best); if (gd < kGapCoarse && gd > 0.0) gl = gd < gl ? gd : gl; }
                     if (t2 > best) { best = t2; arg = s2 + 1; }
                     if (ci[2] & 255u) {
-                        if (TLDS) block_tail(prev, (int)ci[2], l_tsrc, l_tlp, best, arg);
-                        else block_tail(prev, (int)ci[2], a.tsrc, a.tlp, best, arg);
+                        if (TLDS) block_tail(prev, (int)ci[2], l_tsrc, l_tlp, best, arg, gl);
+                        else block_tail(prev, (int)ci[2], a.tsrc, a.tlp, best, arg, gl);
                     }
                     const double v = best + funcl_m(yt, cd[0], c0, den, rden);
                     cur[j] = v;
@@ -248,8 +265,8 @@ void gen_vit_block(BlockArgs a)
                     const bool up = tt > -INFINITY;
                     double best = up ? tt : -INFINITY;
                     int arg = up ? s0 + 1 : 1;
-                    if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg);
-                    else block_tail(prev, ti, a.tsrc, a.tlp, best, arg);
+                    if (TLDS) block_tail(prev, ti, l_tsrc, l_tlp, best, arg, gl);
+                    else block_tail(prev, ti, a.tsrc, a.tlp, best, arg, gl);
                     const double v = best + funcl_m(yt, a.mean[j], c0, den, rden);
                     cur[j] = v;
                     if (own) psi[m] = (int16_t)arg;
@@ -278,17 +295,18 @@ void gen_vit_block(BlockArgs a)
                 double best = up ? tt : -INFINITY;
                 int arg = up ? s0 + 1 : 1;
                 if (GCOL) {
-                    if (TLDS) block_tail(prevg, ti, l_tsrc, l_tlp, best, arg);
-                    else block_tail(prevg, ti, a.tsrc, a.tlp, best, arg);
+                    if (TLDS) block_tail(prevg, ti, l_tsrc, l_tlp, best, arg, gl);
+                    else block_tail(prevg, ti, a.tsrc, a.tlp, best, arg, gl);
                 } else {
-                    if (TLDS) block_tail(prevl, ti, l_tsrc, l_tlp, best, arg);
-                    else block_tail(prevl, ti, a.tsrc, a.tlp, best, arg);
+                    if (TLDS) block_tail(prevl, ti, l_tsrc, l_tlp, best, arg, gl);
+                    else block_tail(prevl, ti, a.tsrc, a.tlp, best, arg, gl);
                 }
                 const double v = best + q;
                 if (GCOL) gcol[par * S + j] = v; else sh[par * CS + j] = v;
                 if (own) psi[m] = (int16_t)arg;
             }
         }
+        if (own) publish_gap(a.gapmin, c, gl);
     }
     __syncthreads();
     for (int j = tid; j < S; j += nt)
@@ -339,6 +357,7 @@ void gen_vit_block1(BlockArgs a)
     }
     double ynext = a.y[w + 1 < e ? w + 1 : w];
     for (int64_t t = w + 1; t < e; t++) {
+        double gl = INFINITY;
         const double yt = ynext;
         ynext = a.y[t + 1 < e ? t + 1 : t];
         const bool own = t >= s;
@@ -353,7 +372,7 @@ void gen_vit_block1(BlockArgs a)
         if (has_b) {
             const double tt = col[bs0] + bl0;
             if (tt > best) { best = tt; arg = bs0 + 1; }
-            block_tail(col, bti, l_tsrc, l_tlp, best, arg);
+            block_tail(col, bti, l_tsrc, l_tlp, best, arg, gl);
         }
         lds_barrier();  // every read of sample t-1 has returned: overwrite in place
 #pragma unroll
@@ -367,6 +386,7 @@ void gen_vit_block1(BlockArgs a)
             col[bj] = v;
             if (own) a.T2c[(int64_t)a.nms * t + tid] = (int16_t)arg;
         }
+        if (own) publish_gap(a.gapmin, c, gl);
     }
     __syncthreads();
     for (int j = tid; j < S; j += nt) a.endv[(int64_t)c * S + j] = col[j];
@@ -417,6 +437,7 @@ void gen_vit_blockG(BlockArgs a, const double *__restrict__ lpdict_g, int ndict,
     double ynext = a.y[w + 1 < e ? w + 1 : w];
     __syncthreads();
     for (int64_t t = w + 1; t < e; t++) {
+        double gl = INFINITY;
         const double yt = ynext;
         ynext = a.y[t + 1 < e ? t + 1 : t];
         __threadfence_block();
@@ -446,10 +467,11 @@ void gen_vit_blockG(BlockArgs a, const double *__restrict__ lpdict_g, int ndict,
             const bool up = tt > -INFINITY;
             double best = up ? tt : -INFINITY;
             int arg = up ? r.s0 + 1 : 1;
-            block_tail(prev, r.ti, l_tsrc, l_tlp, best, arg);
+            block_tail(prev, r.ti, l_tsrc, l_tlp, best, arg, gl);
             cur[r.j] = best + funcl_m(yt, r.mean, c0, den, rden);
             if (own) a.T2c[(int64_t)a.nms * t + m] = (int16_t)arg;
         }
+        if (own) publish_gap(a.gapmin, c, gl);
     }
     __threadfence_block();
     __syncthreads();
@@ -460,13 +482,14 @@ void gen_vit_blockG(BlockArgs a, const double *__restrict__ lpdict_g, int ndict,
 // c-1), both at sample c*B-1.  diag[0] counts failing boundaries, diag[2] holds the largest spread.
 __global__ __launch_bounds__(256) void k_block_check(const double *__restrict__ endv,
                                                      const double *__restrict__ warmv, int S,
-                                                     unsigned long long *diag)
+                                                     unsigned long long *diag,
+                                                     double *__restrict__ frame)  // [nblk][2]
 {
-    __shared__ double smin[256], smax[256];
+    __shared__ double smin[256], smax[256], sabs[256];
     __shared__ int sbad[256];
     const int c = blockIdx.x + 1, tid = threadIdx.x;
     const double *wv = warmv + (int64_t)c * S, *ev = endv + (int64_t)(c - 1) * S;
-    double lo = INFINITY, hi = -INFINITY;
+    double lo = INFINITY, hi = -INFINITY, mabs = 0.0;
     int bad = 0;
     for (int j = tid; j < S; j += 256) {
         const double a = wv[j], b = ev[j];
@@ -475,17 +498,19 @@ __global__ __launch_bounds__(256) void k_block_check(const double *__restrict__ 
             const double d = a - b;
             lo = d < lo ? d : lo;
             hi = d > hi ? d : hi;
+            mabs = fabs(a) > mabs ? fabs(a) : mabs;
         } else if (fa != fb || a != a || b != b) {
             bad = 1;  // reachable in one frame only, or NaN
         }
     }
-    smin[tid] = lo; smax[tid] = hi; sbad[tid] = bad;
+    smin[tid] = lo; smax[tid] = hi; sbad[tid] = bad; sabs[tid] = mabs;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (tid < o) {
             smin[tid] = smin[tid + o] < smin[tid] ? smin[tid + o] : smin[tid];
             smax[tid] = smax[tid + o] > smax[tid] ? smax[tid + o] : smax[tid];
             sbad[tid] |= sbad[tid + o];
+            sabs[tid] = sabs[tid + o] > sabs[tid] ? sabs[tid + o] : sabs[tid];
         }
         __syncthreads();
     }
@@ -494,7 +519,29 @@ __global__ __launch_bounds__(256) void k_block_check(const double *__restrict__ 
         if (sbad[0]) spread = INFINITY;
         if (!(spread <= kSpreadTol)) atomicAdd(&diag[0], 1ull);
         atomicMax(&diag[2], (unsigned long long)__double_as_longlong(spread));
+        // block c's frame = block c-1's frame + (end column of c-1) - (warm column of c)
+        frame[2 * c] = (smax[0] >= smin[0]) ? -0.5 * (smax[0] + smin[0]) : 0.0;
+        frame[2 * c + 1] = sabs[0];
     }
+}
+
+// Near-ties: a block whose smallest non-zero candidate gap is below the rounding granularity the
+// REFERENCE's trellis has there (|its values| ~ |frame offset| + |block values|) may have told two
+// candidates apart that the reference rounds to a tie.  diag[7] counts such blocks; the host-buffer
+// entry point then decodes with the strict engine (duplicate templates are the systematic case).
+__global__ void k_block_ties(const double *__restrict__ frame, const unsigned long long *__restrict__ gapmin,
+                             int nblk, unsigned long long *diag)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double off = 0.0;
+    unsigned long long n = 0;
+    for (int c = 1; c < nblk; c++) {  // block 0 works in the reference's own frame
+        off += frame[2 * c];
+        const double mag = fabs(off) + frame[2 * c + 1] + 1.0;
+        const double gap = __longlong_as_double((long long)gapmin[c]);
+        if (gap <= 64.0 * 2.220446049250313e-16 * mag) n++;
+    }
+    diag[7] = n;
 }
 
 // Back-pointer lookup.  bt[j] > 0: the only source of state j+1; bt[j] <= 0: minus the index of
@@ -828,8 +875,10 @@ int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t
     if ((rc = dalloc(&g->d_endv, nb * S, &g->bytes)) || (rc = dalloc(&g->d_warmv, nb * S, &g->bytes)) ||
         (rc = dalloc(&g->d_fmap, nb * S, &g->bytes)) || (rc = dalloc(&g->d_merged, nb, &g->bytes)) ||
         (rc = dalloc(&g->d_endstate, nb, &g->bytes)) || (rc = dalloc(&g->d_fconst, nb, &g->bytes)) || (rc = dalloc(&g->d_llpart, 3 * nb, &g->bytes)) ||
-        (rc = dalloc(&g->d_bdiag, 8, &g->bytes)))
+        (rc = dalloc(&g->d_bdiag, 8, &g->bytes)) || (rc = dalloc(&g->d_gapmin, nb, &g->bytes)) ||
+        (rc = dalloc(&g->d_frame, 2 * nb, &g->bytes)))
         return rc;
+    HS_HIP(hipMemset(g->d_frame, 0, 2 * nb * sizeof(double)));
     if (!g->blk_cols_lds && !g->blk_onecol && (rc = dalloc(&g->d_blkbuf, nb * 2 * S, &g->bytes)))
         return rc;
     HS_HIP(hipMemset(g->d_bdiag, 0, 8 * sizeof(unsigned long long)));
@@ -839,7 +888,7 @@ int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t
 void blocked_destroy(GenericDev *g)
 {
     void *ptrs[] = {g->d_lp0, g->d_src0, g->d_tinfo, g->d_tsrc, g->d_tlp, g->d_endv, g->d_warmv,
-                    g->d_fmap, g->d_merged, g->d_endstate, g->d_llpart, g->d_bdiag, g->d_blkbuf, g->d_ms, g->d_bt, g->d_fconst, g->d_lpdict, g->d_lpidx};
+                    g->d_fmap, g->d_merged, g->d_endstate, g->d_llpart, g->d_bdiag, g->d_blkbuf, g->d_ms, g->d_bt, g->d_fconst, g->d_lpdict, g->d_lpidx, g->d_gapmin, g->d_frame};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -874,7 +923,7 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     a.c0 = -kLog2Pi - g->lsig;
     a.den = 2.0 * (g->sigma * g->sigma);
     a.rden = 1.0 / a.den;
-    a.T2c = g->d_T2; a.endv = g->d_endv; a.warmv = g->d_warmv;
+    a.T2c = g->d_T2; a.endv = g->d_endv; a.warmv = g->d_warmv; a.gapmin = g->d_gapmin;
     a.gbuf = g->blk_cols_lds ? nullptr : g->d_blkbuf;
     size_t lds = (g->blk_cols_lds ? 2 * (S + 1) * 8 : 0) + (g->blk_tail_lds ? (size_t)g->ntail * 12 + 8 : 0);
     // register-cached sweep: wave-specialised (nbthr phase-B threads + phase-A threads with <= 2
@@ -890,6 +939,7 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     }
     a.nbthr = nbthr;
     HS_HIP(hipMemsetAsync(g->d_bdiag, 0, 8 * sizeof(unsigned long long), st));
+    HS_HIP(hipMemsetAsync(g->d_gapmin, 0x7f, (size_t)g->nblk * sizeof(unsigned long long), st));  // huge
     int rc;
     const bool gcol = !g->blk_cols_lds, tl = g->blk_tail_lds;
     if (g->blk_onecol) {
@@ -935,9 +985,11 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     const int nb = (int)g->nblk;
     if (nb > 1) {
         hipLaunchKernelGGL(k_block_check, dim3(nb - 1), dim3(256), 0, st, g->d_endv, g->d_warmv, (int)S,
-                           g->d_bdiag);
+                           g->d_bdiag, g->d_frame);
         HS_HIP(hipGetLastError());
     }
+    hipLaunchKernelGGL(k_block_ties, dim3(1), dim3(64), 0, st, g->d_frame, g->d_gapmin, nb, g->d_bdiag);
+    HS_HIP(hipGetLastError());
     // backtrace: rows of T2c staged W at a time; bt in LDS when it fits
     const int nms1 = std::max(g->nms, 1);
     int W = (int)std::max<int64_t>(1, std::min<int64_t>(64, (32 * 1024) / (nms1 * 2)));

@@ -31,7 +31,8 @@ struct GenericDev {
     int nms = 0;
     int16_t *d_fmap = nullptr, *d_endstate = nullptr, *d_fconst = nullptr;
     int64_t *d_merged = nullptr;
-    unsigned long long *d_bdiag = nullptr;
+    unsigned long long *d_bdiag = nullptr, *d_gapmin = nullptr;
+    double *d_frame = nullptr;  // per block: frame constant relative to the previous block, |values|
     int64_t upd_bytes = 0;
     int threads = 256;
     int64_t bytes = 0;

@@ -196,7 +196,11 @@ int hmmsort_plan_mstep(hmmsort_plan *plan, const double *d_stats, double *d_out,
  *           pattern of a double), diag[3] / diag[5] = chain boundaries whose forward / backward warm-up
  *           missed the posterior-weighted tolerance 1e-9, diag[4] / diag[6] = the largest such
  *           error (IEEE-754 bit pattern of a double).  Viterbi calls fill [0..1], E-step calls
- *           [3..6]. */
+ *           [3..6].  Blocked engine: diag[0], diag[2] as above for its block boundaries, and
+ *           diag[7] = blocks in which two candidates of a maximum came closer than the rounding
+ *           granularity of the reference's trellis at that point (near-ties, e.g. duplicate
+ *           templates): the blocks' additive frames may then break a tie the reference breaks by
+ *           list order; hmmsort_viterbi re-decodes such signals with the strict engine. */
 int hmmsort_plan_diagnostics(hmmsort_plan *plan, void *stream, int64_t diag[8]);
 
 /* reconstruct_signal (reconstruction.jl:1-10) and unroll_mlseq (extraction.jl:4-13) of a decoded

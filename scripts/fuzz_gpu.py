@@ -25,6 +25,7 @@ def run(n_cases, seed, verbose=True):
 
 
 STRESS = bool(int(__import__("os").environ.get("FUZZ_STRESS", "0")))  # bigger, busier models
+TIES = bool(int(__import__("os").environ.get("FUZZ_TIES", "0")))     # duplicate templates: tie-breaking rules
 ENGINE = int(__import__("os").environ.get("FUZZ_ENGINE", "0"))        # 0 auto, 1 strict, 3 blocked (decode)
 
 
@@ -41,6 +42,10 @@ def one_case(rng, case):
         temps = np.asfortranarray(np.stack([H.create_spike_template(K, rng.uniform(1.5, 5), rng.uniform(0.2, 1.0),
                                                                     rng.uniform(0.1, 0.4)) for _ in range(N)], 1))
         pp = rng.uniform(5e-4, 8e-3, N) * min(1.0, 30.0 / K) * (rng.choice([1.0, 3.0, 8.0]) if STRESS else 1.0)
+        if TIES and N >= 2:   # identical templates with identical rates: every spike is an exact tie
+            temps[:, 1] = temps[:, 0]; pp[1] = pp[0]
+            if N >= 4:
+                temps[:, 3] = temps[:, 2]; pp[3] = pp[2]
         y = H.create_signal(T, sigma, pp, temps, seed=int(rng.integers(1, 1 << 30)))
         sm = H.StateMatrix.create(N, K, np.log(pp), ov)
         osm = to_oracle_sm(O, sm)

@@ -189,3 +189,24 @@ def test_golden_overlap_fixture_through_blocked_engine(H):
     x, ll = H.viterbi(g["y"], sm, np.asfortranarray(g["temps"]), 0.3)
     assert H.get_option("last_escalations") == 0
     assert np.array_equal(x, g["x"]) and abs(ll - float(g["ll"])) <= LL_RTOL * abs(float(g["ll"]))
+
+
+def test_duplicate_templates_near_ties_are_detected(O, H):
+    # two pairs of identical templates with identical rates in an overlap model: whole families of
+    # candidates differ by rounding only.  The blocks' additive frames can then separate what the
+    # reference rounds to a tie (and resolves by list order): such blocks are counted in diag[7] and
+    # the host-buffer entry point decodes with the strict engine (found by scripts/fuzz_gpu.py with
+    # FUZZ_TIES=1: 902 samples differed on this kind of input before the check existed)
+    K, N, T = 23, 4, 31_099
+    base = _templates(H, K, 2)
+    temps = np.asfortranarray(np.stack([base[:, 0], base[:, 0], base[:, 1], base[:, 1]], 1))
+    pp = [0.004, 0.004, 0.003, 0.003]
+    sm = H.StateMatrix.create(N, K, np.log(pp), True)
+    for seed in (1, 2, 3):
+        y = H.create_signal(T, 0.28, pp, temps, seed=seed)
+        H.set_option("engine", H.ENGINE_AUTO)
+        H.set_option("block", 512)
+        H.set_option("halo", 256)
+        x, ll = H.viterbi(y, sm, temps, 0.28)
+        xo, llo = O.viterbi(y, to_oracle_sm(O, sm), temps, 0.28)
+        assert np.array_equal(x, xo) and abs(ll - llo) <= LL_RTOL * abs(llo)
