@@ -539,7 +539,7 @@ __global__ void k_block_ties(const double *__restrict__ frame, const unsigned lo
         off += frame[2 * c];
         const double mag = fabs(off) + frame[2 * c + 1] + 1.0;
         const double gap = __longlong_as_double((long long)gapmin[c]);
-        if (gap <= 64.0 * 2.220446049250313e-16 * mag) n++;
+        if (gap <= 8.0 * 2.220446049250313e-16 * mag) n++;  // a few ulps of the reference's values
     }
     diag[7] = n;
 }
