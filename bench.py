@@ -341,7 +341,7 @@ def main():
         return {"model": "N=2 K=%d allow_overlaps=true, %d states" % (Ko, smo.nstates), "samples": To,
                 "engine": {1: "strict", 2: "ring", 3: "blocked"}.get(io["engine"], io["engine"]),
                 "block": io["block"], "halo": io["halo"], "Msamples_s": To / per / 1e6,
-                "boundary_check_fails": d[0], "max_boundary_spread": d[2]}
+                "boundary_check_fails": d[0], "max_boundary_spread": d[2], "near_tie_blocks": d[7]}
     ov = overlap_decode() if (rank == 0 and world == 1) else None
 
     if rank == 0:

@@ -14,7 +14,9 @@ bad = 0
 for case in range(n_cases):
     N = int(rng.integers(1, 7)); K = int(rng.integers(17, 80)); T = int(rng.integers(500_000, 6_000_000))
     if OV:
-        N = int(rng.integers(2, 4)); K = int(rng.integers(6, 45 if N == 2 else 22)); T = int(rng.integers(60_000, 500_000))
+        N = int(rng.integers(2, 5)); K = int(rng.integers(6, {2: 61, 3: 61, 4: 50}[N])); T = int(rng.integers(60_000, 300_000))
+        if 1 + N * (K - 1) + N * (N - 1) // 2 * (K - 1) ** 2 > 8000:
+            T = min(T, 120_000)   # the strict engine decodes ~20-100 k samples/s at these sizes
     sigma = float(rng.uniform(0.15, 0.6))
     temps = np.asfortranarray(np.stack([H.create_spike_template(K, rng.uniform(1.5, 5), rng.uniform(0.2, 1.0),
                                                                 rng.uniform(0.1, 0.4)) for _ in range(N)], 1))
