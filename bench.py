@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--neurons", type=int, default=4, help="templates (reference N); 4 = headline")
     ap.add_argument("--states", type=int, default=60, help="states per template (reference K)")
+    ap.add_argument("--engine", type=int, default=0, help="0 auto (wave), 2 lane-per-chain ring engine, 4 wave")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--halo", type=int, default=0)
     args = ap.parse_args()
@@ -169,6 +170,7 @@ def main():
     y = H.create_signal(T, sigma, pp, temps, seed=seed)
     sm = H.StateMatrix.create(N, K, np.log(pp), False)
     S = sm.nstates
+    H.set_option("engine", args.engine)
     H.set_option("block", args.block)
     H.set_option("halo", args.halo)
     T_total = T
@@ -181,7 +183,8 @@ def main():
         plan.set_shard(o_lo, o_hi, first, last)
         args.pooled = True   # the shard statistics must be summed before the M-step
     info = plan.info()
-    assert info["engine"] == H.ENGINE_RING
+    assert info["engine"] in (H.ENGINE_RING, H.ENGINE_WAVE)
+    engine_name = {H.ENGINE_RING: "ring", H.ENGINE_WAVE: "wave"}[info["engine"]]
 
     stream = torch.cuda.current_stream().cuda_stream
     dy = torch.from_numpy(y).to(dev)
@@ -359,7 +362,7 @@ def main():
                                    "(forward-backward + sufficient statistics + M-step finish)"
                                    % (N, K, N, K, S, T),
                        "channels": world, "samples_per_channel": T, "states": S,
-                       "engine": "ring", "block": info["block"], "halo": info["halo"],
+                       "engine": engine_name, "block": info["block"], "halo": info["halo"],
                        "chains": info["nchains"], "seed": 1234, "pooled_allreduce": bool(args.pooled),
                        "time_sharded": bool(args.time_sharded)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,

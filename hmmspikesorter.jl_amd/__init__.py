@@ -5,7 +5,7 @@ The directory name is the one the build contract fixes; it is not a valid Python
 import it through the root-level shim:  `import hmmsort_amd`.
 """
 from . import _lib, dist, synth
-from ._lib import (ENGINE_AUTO, ENGINE_BLOCKED, ENGINE_RING, ENGINE_STRICT, HmmsortError, device_count,
+from ._lib import (ENGINE_AUTO, ENGINE_BLOCKED, ENGINE_RING, ENGINE_STRICT, ENGINE_WAVE, HmmsortError, device_count,
                    get_option, set_option)
 from .api import (HMMSpikeTemplateModel, HMMSpikingModel, StateMatrix, backward, extract_spiketimes,
                   fit, forward,
@@ -19,4 +19,4 @@ __all__ = ["StateMatrix", "HMMSpikeTemplateModel", "HMMSpikingModel", "forward",
            "update", "train_model", "train_step", "viterbi", "reconstruct_signal", "unroll_mlseq",
            "fit", "predict", "extract_spiketimes", "Plan", "create_signal", "create_spike_template", "HmmsortError",
            "set_option", "get_option", "device_count", "ENGINE_AUTO", "ENGINE_STRICT",
-           "ENGINE_RING", "ENGINE_BLOCKED", "get_lp", "sort_data"]
+           "ENGINE_RING", "ENGINE_BLOCKED", "ENGINE_WAVE", "get_lp", "sort_data"]

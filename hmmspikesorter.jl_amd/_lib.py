@@ -16,7 +16,7 @@ TRANS_DTYPE = np.dtype([("src", np.int64), ("dst", np.int64), ("lp", np.float64)
 assert TRANS_DTYPE.itemsize == 24
 
 OK, EINVAL, ENOMEM, EHIP, ENOCONV, EUNSUP = 0, -1, -2, -3, -4, -5
-ENGINE_AUTO, ENGINE_STRICT, ENGINE_RING, ENGINE_BLOCKED = 0, 1, 2, 3
+ENGINE_AUTO, ENGINE_STRICT, ENGINE_RING, ENGINE_BLOCKED, ENGINE_WAVE = 0, 1, 2, 3, 4
 
 
 class HmmsortError(RuntimeError):

@@ -211,7 +211,7 @@ class _EMSession:
                 self.close()
                 self.key = key
                 self.plan = Plan(len(self.X), lA, mu, sigma)
-                if self.plan.info()["engine"] != _lib.ENGINE_RING:
+                if self.plan.info()["engine"] not in (_lib.ENGINE_RING, _lib.ENGINE_WAVE):
                     self.close()                # remembered through self.key: not retried
             elif self.plan is not None:
                 self.plan.set_model(lA, mu, sigma)
@@ -352,18 +352,20 @@ def fit(templates, X, chunksize=None):
             j = min(i + chunksize - 1, n)
             k = j - i + 1
             l = 1
-            if twins:
+            if k not in plans:
+                plans[k] = Plan(k, lA, mu, sigma)
+            plan = plans[k]
+            if twins and plan.info()["engine"] == _lib.ENGINE_RING:
+                # the lane-per-chain ring engine has no run-time near-tie detector (the wave and
+                # blocked engines count near-ties in diag[7])
                 x, _ll = viterbi(X[i - 1:j], lA, mu, sigma)
                 plan = None
             else:
-                if k not in plans:
-                    plans[k] = Plan(k, lA, mu, sigma)
-                plan = plans[k]
                 plan.viterbi(dX.data_ptr() + (i - 1) * 8, dx, dll)
             dg = plan.diagnostics() if plan is not None else None
             if plan is None:
                 pass
-            elif dg[0] != 0 or (plan.info()["engine"] == _lib.ENGINE_BLOCKED and dg[7] != 0):  # failed check / near-ties:
+            elif dg[0] != 0 or (plan.info()["engine"] in (_lib.ENGINE_BLOCKED, _lib.ENGINE_WAVE) and dg[7] != 0):  # failed check / near-ties:
                 x, _ll = viterbi(X[i - 1:j], lA, mu, sigma)   # the escalating entry point
             else:
                 x, _ll = dx[:k].cpu().numpy(), float(dll.cpu()[0])

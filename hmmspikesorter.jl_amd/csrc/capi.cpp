@@ -6,6 +6,7 @@
 
 #include "hmmsort_internal.h"
 #include "ring_common.h"
+#include "wave_common.h"
 
 using namespace hmmsort;
 
@@ -15,6 +16,9 @@ struct hmmsort_plan {
     int64_t engine = HMMSORT_ENGINE_STRICT;
     GenericDev *gen = nullptr;
     RingDev *ring = nullptr;
+    WaveDev *wave = nullptr;
+    int64_t C = 1;                      // channels (batched wave plans)
+    std::vector<HostModel> models;      // per-channel models of a batched plan (models[0] == model)
 };
 
 namespace {
@@ -85,13 +89,23 @@ int plan_create_engine(hmmsort_plan **out, int64_t T, const int16_t *states, int
     rc = build_host_model(p->model, states, N, K, S, tr, R, mu, sigma);
     if (rc) return rc;
     std::string why;
+    const bool wave_ok = wave_supported(p->model, T, &why);
+    if (engine_req == HMMSORT_ENGINE_WAVE && !wave_ok) {
+        set_error("wave engine unavailable for this model/signal: %s", why.c_str());
+        return HMMSORT_EUNSUP;
+    }
     const bool ring_ok = ring_supported(p->model, T, &why);
     if (engine_req == HMMSORT_ENGINE_RING && !ring_ok) {
         set_error("ring engine unavailable for this model/signal: %s", why.c_str());
         return HMMSORT_EUNSUP;
     }
     const bool want_ring = engine_req == HMMSORT_ENGINE_AUTO || engine_req == HMMSORT_ENGINE_RING;
-    if (want_ring && ring_ok) {
+    if ((engine_req == HMMSORT_ENGINE_AUTO || engine_req == HMMSORT_ENGINE_WAVE) && wave_ok) {
+        p->engine = HMMSORT_ENGINE_WAVE;
+        p->models.assign(1, p->model);
+        rc = wave_create(&p->wave, p->models, T, options().block,
+                         halo_req >= 0 ? halo_req : options().halo);
+    } else if (want_ring && ring_ok) {
         p->engine = HMMSORT_ENGINE_RING;
         rc = ring_create(&p->ring, p->model, T, options().block,
                          halo_req >= 0 ? halo_req : options().halo);
@@ -147,7 +161,7 @@ int hmmsort_set_option(const char *key, int64_t value)
     HS_CHECK(key, HMMSORT_EINVAL, "set_option: null key");
     Options &o = options();
     if (!strcmp(key, "engine")) {
-        HS_CHECK(value >= 0 && value <= 3, HMMSORT_EINVAL, "set_option: engine must be 0..3");
+        HS_CHECK(value >= 0 && value <= 4, HMMSORT_EINVAL, "set_option: engine must be 0..4");
         o.engine = value;
     } else if (!strcmp(key, "block")) {
         HS_CHECK(value >= 0, HMMSORT_EINVAL, "set_option: block must be >= 0");
@@ -201,7 +215,11 @@ int hmmsort_plan_set_model(hmmsort_plan *p, const hmm_trans *tr, int64_t R, cons
     std::vector<int16_t> st = p->model.states;
     int rc = build_host_model(m, st.data(), p->model.N, p->model.K, p->model.S, tr, R, mu, sigma);
     if (rc) return rc;
-    if (p->ring) {
+    if (p->wave) {
+        HS_CHECK(m.ring.valid, HMMSORT_EUNSUP, "plan_set_model: new model is not a ring model");
+        rc = wave_set_model(p->wave, 0, m);
+        if (!rc) p->models[0] = m;
+    } else if (p->ring) {
         HS_CHECK(m.ring.valid, HMMSORT_EUNSUP, "plan_set_model: new model is not a ring model");
         rc = ring_set_model(p->ring, m);
     } else {
@@ -217,6 +235,7 @@ int hmmsort_plan_destroy(hmmsort_plan *p)
     if (!p) return HMMSORT_OK;
     if (p->gen) generic_destroy(p->gen);
     if (p->ring) ring_destroy(p->ring);
+    if (p->wave) wave_destroy(p->wave);
     delete p;
     return HMMSORT_OK;
 }
@@ -226,7 +245,10 @@ int hmmsort_plan_info(const hmmsort_plan *p, int64_t *engine, int64_t *block, in
 {
     HS_CHECK(p, HMMSORT_EINVAL, "plan_info: null plan");
     int64_t b = 0, h = 0, n = 0, w = 0;
-    if (p->ring) {
+    if (p->wave) {
+        b = p->wave->g.B; h = p->wave->g.Hw - 1; n = (int64_t)p->wave->g.nch * p->wave->g.C;
+        w = p->wave->bytes;
+    } else if (p->ring) {
         ring_geometry(p->ring, &b, &h, &n);
         w = ring_workspace_bytes(p->ring);
     } else if (p->gen) {
@@ -244,6 +266,7 @@ int hmmsort_plan_info(const hmmsort_plan *p, int64_t *engine, int64_t *block, in
 int hmmsort_plan_bind(hmmsort_plan *p, const double *d_y, void *stream)
 {
     HS_CHECK(p && d_y, HMMSORT_EINVAL, "plan_bind: null argument");
+    if (p->wave) return wave_bind(p->wave, d_y, (hipStream_t)stream);
     if (p->ring) return ring_bind(p->ring, d_y, (hipStream_t)stream);
     return HMMSORT_OK;
 }
@@ -251,6 +274,7 @@ int hmmsort_plan_bind(hmmsort_plan *p, const double *d_y, void *stream)
 int hmmsort_plan_unbind(hmmsort_plan *p)
 {
     HS_CHECK(p, HMMSORT_EINVAL, "plan_unbind: null plan");
+    if (p->wave) p->wave->bound_y = nullptr;
     if (p->ring) p->ring->bound_y = nullptr;
     return HMMSORT_OK;
 }
@@ -260,6 +284,7 @@ int hmmsort_plan_viterbi(hmmsort_plan *p, const double *d_y, int16_t *d_x, doubl
 {
     HS_CHECK(p && d_y && d_x && d_ll, HMMSORT_EINVAL, "plan_viterbi: null argument");
     hipStream_t st = (hipStream_t)stream;
+    if (p->wave) return wave_viterbi(p->wave, d_y, d_x, d_ll, st);
     if (p->ring) return ring_viterbi(p->ring, d_y, d_x, d_ll, st);
     return generic_viterbi(p->gen, d_y, d_x, d_ll, st);
 }
@@ -268,19 +293,25 @@ int hmmsort_plan_decode_estep(hmmsort_plan *p, const double *d_y, int16_t *d_x, 
                               double *d_stats, void *stream)
 {
     HS_CHECK(p && d_y && d_x && d_ll && d_stats, HMMSORT_EINVAL, "plan_decode_estep: null argument");
-    HS_CHECK(p->ring, HMMSORT_EUNSUP, "plan_decode_estep: needs the ring engine");
+    if (p->wave) return wave_decode_estep(p->wave, d_y, d_x, d_ll, d_stats, (hipStream_t)stream);
+    HS_CHECK(p->ring, HMMSORT_EUNSUP, "plan_decode_estep: needs the wave or ring engine");
     return ring_decode_estep_launch(p->ring, d_y, d_x, d_ll, d_stats, (hipStream_t)stream);
 }
 
 int hmmsort_plan_set_shard(hmmsort_plan *p, int64_t own_lo, int64_t own_hi, int first, int last)
 {
     HS_CHECK(p, HMMSORT_EINVAL, "plan_set_shard: null plan");
-    HS_CHECK(p->ring, HMMSORT_EUNSUP, "plan_set_shard: needs the ring engine");
+    HS_CHECK(p->ring || p->wave, HMMSORT_EUNSUP, "plan_set_shard: needs the wave or ring engine");
     HS_CHECK(own_lo >= 0 && own_lo <= own_hi && own_hi <= p->T, HMMSORT_EINVAL,
              "plan_set_shard: owned range [%lld, %lld) outside [0, %lld]", (long long)own_lo,
              (long long)own_hi, (long long)p->T);
     HS_CHECK((!first || own_lo == 0) && (!last || own_hi == p->T), HMMSORT_EINVAL,
              "plan_set_shard: a first/last shard must own its first/last sample");
+    if (p->wave) {
+        p->wave->g.own_lo = own_lo; p->wave->g.own_hi = own_hi;
+        p->wave->g.first = first != 0; p->wave->g.last = last != 0;
+        return HMMSORT_OK;
+    }
     p->ring->g.own_lo = own_lo; p->ring->g.own_hi = own_hi;
     p->ring->g.first = first != 0; p->ring->g.last = last != 0;
     return HMMSORT_OK;
@@ -288,6 +319,7 @@ int hmmsort_plan_set_shard(hmmsort_plan *p, int64_t own_lo, int64_t own_hi, int 
 
 int64_t hmmsort_plan_stats_len(const hmmsort_plan *p)
 {
+    if (p && p->wave) return wave_stats_len(p->wave);
     if (!p || !p->ring) return 0;
     return ring_stats_len(p->ring);
 }
@@ -295,15 +327,17 @@ int64_t hmmsort_plan_stats_len(const hmmsort_plan *p)
 int hmmsort_plan_estep(hmmsort_plan *p, const double *d_y, double *d_stats, void *stream)
 {
     HS_CHECK(p && d_y && d_stats, HMMSORT_EINVAL, "plan_estep: null argument");
+    if (p->wave) return wave_estep(p->wave, d_y, d_stats, (hipStream_t)stream);
     HS_CHECK(p->ring, HMMSORT_EUNSUP,
-             "plan_estep: sufficient-statistics E-step needs the ring engine (use hmmsort_em_step)");
+             "plan_estep: sufficient-statistics E-step needs the wave or ring engine (use hmmsort_em_step)");
     return ring_estep(p->ring, d_y, d_stats, (hipStream_t)stream);
 }
 
 int hmmsort_plan_mstep(hmmsort_plan *p, const double *d_stats, double *d_out, void *stream)
 {
     HS_CHECK(p && d_stats && d_out, HMMSORT_EINVAL, "plan_mstep: null argument");
-    HS_CHECK(p->ring, HMMSORT_EUNSUP, "plan_mstep: needs the ring engine");
+    if (p->wave) return wave_mstep(p->wave, d_stats, d_out, (hipStream_t)stream);
+    HS_CHECK(p->ring, HMMSORT_EUNSUP, "plan_mstep: needs the wave or ring engine");
     return ring_mstep(p->ring, d_stats, d_out, (hipStream_t)stream);
 }
 
@@ -311,14 +345,25 @@ int hmmsort_plan_diagnostics(hmmsort_plan *p, void *stream, int64_t diag[8])
 {
     HS_CHECK(p && diag, HMMSORT_EINVAL, "plan_diagnostics: null argument");
     for (int i = 0; i < 8; i++) diag[i] = 0;
+    if (p->wave) return wave_diagnostics(p->wave, (hipStream_t)stream, diag);
     if (p->ring) return ring_diagnostics(p->ring, (hipStream_t)stream, diag);
     if (p->gen) return generic_diagnostics(p->gen, (hipStream_t)stream, diag);
+    return HMMSORT_OK;
+}
+
+// debugging aid (not part of the documented ABI): raw debug record of the wave engine
+int hmmsort_plan_debug_record(hmmsort_plan *p, double *out64)
+{
+    HS_CHECK(p && out64 && p->wave, HMMSORT_EINVAL, "plan_debug_record: needs a wave plan");
+    HS_HIP(hipDeviceSynchronize());
+    HS_HIP(hipMemcpy(out64, p->wave->dbg, 64 * sizeof(double), hipMemcpyDeviceToHost));
     return HMMSORT_OK;
 }
 
 int hmmsort_plan_profile(hmmsort_plan *p, int enable)
 {
     HS_CHECK(p, HMMSORT_EINVAL, "plan_profile: null plan");
+    if (p->wave) { p->wave->prof_on = enable != 0; return HMMSORT_OK; }
     if (p->ring) return ring_profile_enable(p->ring, enable);
     return HMMSORT_OK;
 }
@@ -329,11 +374,12 @@ int hmmsort_plan_profile_read(hmmsort_plan *p, void *stream, char *names, int64_
     HS_CHECK(p && names && ms && calls && n_out, HMMSORT_EINVAL, "plan_profile_read: null argument");
     *n_out = 0;
     if (names_cap > 0) names[0] = 0;
-    if (!p->ring) return HMMSORT_OK;
+    if (!p->ring && !p->wave) return HMMSORT_OK;
     std::vector<std::string> nm;
     std::vector<double> m;
     std::vector<int64_t> c;
-    int rc = ring_profile_read(p->ring, (hipStream_t)stream, nm, m, c);
+    int rc = p->wave ? wave_profile_read(p->wave, (hipStream_t)stream, nm, m, c)
+                     : ring_profile_read(p->ring, (hipStream_t)stream, nm, m, c);
     if (rc) return rc;
     std::string joined;
     int64_t n = std::min<int64_t>((int64_t)nm.size(), cap);
@@ -357,7 +403,8 @@ int hmmsort_plan_profile_read(hmmsort_plan *p, void *stream, char *names, int64_
 static int64_t next_halo(const hmmsort_plan *p)
 {
     int64_t b = 0, h = 0, n = 0;
-    if (p->ring) ring_geometry(p->ring, &b, &h, &n);
+    if (p->wave) h = p->wave->g.Hw - 1;
+    else if (p->ring) ring_geometry(p->ring, &b, &h, &n);
     else generic_geometry(p->gen, &b, &h, &n);
     return h * 2;
 }
@@ -393,7 +440,8 @@ int hmmsort_viterbi(const double *y, int64_t T, const int16_t *states, int64_t N
         if (pg.p->engine == HMMSORT_ENGINE_STRICT) break;
         int64_t diag[8];
         if ((rc = hmmsort_plan_diagnostics(pg.p, nullptr, diag))) return rc;
-        const bool ties = pg.p->engine == HMMSORT_ENGINE_BLOCKED && diag[7] != 0;
+        const bool ties = (pg.p->engine == HMMSORT_ENGINE_BLOCKED || pg.p->engine == HMMSORT_ENGINE_WAVE) &&
+                          diag[7] != 0;
         if ((diag[0] == 0 && !ties) || !options().escalate) break;
         options().last_escalations = attempt + 1;
         halo = next_halo(pg.p);
@@ -511,29 +559,29 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
         if (pg.p) { hmmsort_plan_destroy(pg.p); pg.p = nullptr; }
         rc = plan_create_engine(&pg.p, T, states, N, K, S, tr, R, mu_inout, sigma, engine, halo);
         if (rc) return rc;
-        if (!pg.p->ring) {
+        if (!pg.p->ring && !pg.p->wave) {
             if (pg.p->engine == HMMSORT_ENGINE_STRICT) break;
             engine = HMMSORT_ENGINE_STRICT;  // materialised alpha/beta are the strict engine's job
             continue;
         }
         const int64_t nlp = N;
         DevBuf dstats, dout;
-        if ((rc = dstats.alloc(ring_stats_len(pg.p->ring) * sizeof(double))) ||
+        if ((rc = dstats.alloc(hmmsort_plan_stats_len(pg.p) * sizeof(double))) ||
             (rc = dout.alloc((K * N + 1 + nlp + S) * sizeof(double))))
             return rc;
-        if ((rc = ring_estep(pg.p->ring, dy.as<double>(), dstats.as<double>(), nullptr))) return rc;
-        if ((rc = ring_mstep(pg.p->ring, dstats.as<double>(), dout.as<double>(), nullptr))) return rc;
+        if ((rc = hmmsort_plan_estep(pg.p, dy.as<double>(), dstats.as<double>(), nullptr))) return rc;
+        if ((rc = hmmsort_plan_mstep(pg.p, dstats.as<double>(), dout.as<double>(), nullptr))) return rc;
         HS_HIP(hipDeviceSynchronize());
         int64_t diag[8];
-        if ((rc = ring_diagnostics(pg.p->ring, nullptr, diag))) return rc;
+        if ((rc = hmmsort_plan_diagnostics(pg.p, nullptr, diag))) return rc;
         if ((diag[3] == 0 && diag[5] == 0) || !options().escalate)
             return unpack_mstep(dout.as<double>(), K, N, S, nlp, mu_inout, sigma_out, lp_out, lp_cap,
                                 n_lp_out, pp_out);
         options().last_escalations = attempt + 1;
         halo = next_halo(pg.p);
         if (attempt >= 3 || halo > T) {
-            HS_CHECK(options().engine != HMMSORT_ENGINE_RING, HMMSORT_ENOCONV,
-                     "em_step: %lld chain boundaries still fail the warm-up check",
+            HS_CHECK(options().engine != HMMSORT_ENGINE_RING && options().engine != HMMSORT_ENGINE_WAVE,
+                     HMMSORT_ENOCONV, "em_step: %lld chain boundaries still fail the warm-up check",
                      (long long)(diag[3] + diag[5]));
             engine = HMMSORT_ENGINE_STRICT;
         }

@@ -1,0 +1,207 @@
+// Shared declarations of the WAVE engine (wave_engine.hip, wave_viterbi.hip, wave_estep.hip): the
+// time-parallel engine for no-overlap ("ring") models, one WAVEFRONT per chain.
+//
+// Structure exploited (reference types.jl:94-113): N deterministic rings of
+// L = K-1 states through one silent state; only the N+1 junction states (silent, each ring's first
+// state) have more than one predecessor, and a ring is a delay line of L samples.  Hence, given the
+// ring exits X_a(t) = P_a(t-L) of the last L samples, the recursion over the NEXT W <= L samples is
+// first order in one scalar (delta / alpha / beta of the silent state):
+//     Viterbi   D0(t) = max(D0(t-1) + a_t, b_t)            (max-plus)
+//     forward   x_t   = al_t * x_{t-1} + be_t              (linear, per-lane scaled)
+// Both are associative, so a wavefront advances W = min(L, 64) samples per step with a 6-level
+// cross-lane scan; everything else of those W samples is lane-parallel.  The delay lines live in
+// LDS (N x (L+W) doubles per wavefront), never in HBM; the recording is cut into a few thousand
+// long chains (one per wavefront, ~4 per SIMD), so the warm-up in front of every chain is a few
+// per cent of the sweep instead of half of it (lane-per-chain ring engine, ring_*.hip).
+// All per-sample arrays are in natural time order.  tests/wave_model.py is the executable
+// specification of the arithmetic (checked against the CPU oracle).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "hmmsort_internal.h"
+#include "ring_common.h"   // ProfEntry, dispatch_N, kRingMaxN
+
+namespace hmmsort {
+
+constexpr double kScFloor = -700.0;  // entry log-probabilities below this stay in the exponent
+
+struct WaveGeom {
+    int64_t T;        // samples per channel
+    int C;            // channels (batched plans; 1 otherwise)
+    int N, L;         // rings, ring length
+    int W;            // samples per super-step = min(L, 64)
+    int RB;           // delay-line length in LDS (>= L + W, multiple of 32)
+    int B;            // chain length (owned samples), multiple of 64
+    int Hw;           // forward-type warm-up: chain c > 0 starts at tc - Hw, Hw - 1 = m*W steps
+    int He;           // backward warm-up in samples (multiple of W)
+    int nch;          // chains per channel
+    int EB, epw, PW;  // psi packing: bits per entry (incl. the near-tie flag), entries/word, words
+    int Bb, Hb;       // backtrace segments: length and walk-in (multiples of 64)
+    int64_t nseg;     // backtrace segments per channel
+    int64_t own_lo, own_hi;  // time shard (hmmsort_plan_set_shard)
+    int first, last;
+};
+
+// per-channel model constants (device table, wave-uniform scalar loads)
+struct WaveConst {
+    double c00, mean0, den, A, sc0, P00;
+    double c0[kRingMaxN], cend[kRingMaxN], sc[kRingMaxN], CP0[kRingMaxN], PEND[kRingMaxN];
+    double xishift[kRingMaxN];                 // c0_a - sc_a: log Xi_a = xishift + log Xi'_a
+    double cx[kRingMaxN * kRingMaxN];          // [a*N+b]: (a,L) -> (b,1)
+    double CPX[kRingMaxN * kRingMaxN];         // [a*N+b] = exp(cx[a,b] - sc_b), 0 on the diagonal
+};
+
+struct WaveDev {
+    WaveGeom g{};
+    bool prof_on = false;
+    const double *bound_y = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr;
+    std::vector<ProfEntry> prof;
+    int64_t S = 0, K = 0;
+    std::vector<RingModel> ring;      // per channel
+    std::vector<std::vector<double>> mean;
+    std::vector<double> sigma;
+    // device model tables (per channel)
+    WaveConst *d_cst = nullptr;       // C
+    double *d_mean = nullptr;         // C x S
+    double *d_msq = nullptr;          // C x N*(L+1)
+    double *d_cint = nullptr;         // C x N*(L+1)
+    double *d_ctab = nullptr;         // C x (1 + 2N + N*N + N*L)
+    int16_t *d_states = nullptr;      // N x S
+    // per-sample arrays, natural layout [C][...][T]
+    double *Rf = nullptr;             // C x N x T ring scores
+    double *virt = nullptr;           // C x N x (L+1) virtual onsets V[a][j]
+    double *ysum = nullptr;           // C x 2: sum y, sum y^2
+    uint32_t *psi = nullptr;          // PW x C x T
+    double *vpre = nullptr, *vend = nullptr;   // C*nch x (1 + N*L) Viterbi boundary states
+    int32_t *vfail = nullptr;         // C*nch
+    int32_t *bstate = nullptr;        // C*nseg
+    int32_t *redo = nullptr;          // stitch list
+    int32_t *final_state = nullptr;   // C
+    double *part = nullptr;           // reduction partials (ll)
+    double *FA0 = nullptr;            // C x T   log alpha(silent)
+    double *FV = nullptr;             // C x N x T scaled onset masses
+    double *FREF = nullptr;           // C x T   their scale
+    double *fpre = nullptr;           // C*nch x (1 + L*(N+1)): warm-up copy of la0(tc-1), fv/fref of tc-L..tc-1
+    double *bpre = nullptr, *bown = nullptr;   // C*nch x (1 + L*(N+1)): backward boundary values (warm-up / own)
+    double *rho = nullptr;            // C x N x T onset posteriors
+    double *Zc = nullptr;             // C*nch
+    double *partS = nullptr;          // C*nch x (2N+3)
+    double *partG = nullptr;          // gsum partials
+    double *yhead = nullptr;          // C x (N*L + 2): Yn_a(t), t < L (logs) | lb0(0) | z0
+    double *extra = nullptr;          // C x 3*N*L
+    double *pp = nullptr;             // C x S
+    int64_t *diag = nullptr;          // 8
+    double *dbg = nullptr;            // 64 doubles: debug record of the first failing certificate
+    int64_t bytes = 0;
+    int nparts = 0, gparts = 0;
+};
+
+struct WProfScope {
+    WaveDev *r;
+    hipStream_t st;
+    ProfEntry e;
+    WProfScope(WaveDev *r_, const char *name, hipStream_t st_) : r(r_), st(st_)
+    {
+        e.name = name; e.a = nullptr; e.b = nullptr;
+        if (r->prof_on && hipEventCreate(&e.a) == hipSuccess && hipEventCreate(&e.b) == hipSuccess)
+            (void)hipEventRecord(e.a, st);
+    }
+    ~WProfScope()
+    {
+        if (r->prof_on && e.a && e.b) {
+            (void)hipEventRecord(e.b, st);
+            r->prof.push_back(e);
+        }
+    }
+};
+#define WPROF(r, name, st) WProfScope wprof_scope_(r, name, st)
+
+// psi packing with one near-tie flag bit per entry
+constexpr int wpsi_bits_c(int N) { int b = 1; while ((1 << b) < N + 1) b++; return b + 1; }
+constexpr int wpsi_epw_c(int N) { return 32 / wpsi_bits_c(N); }
+constexpr int wpsi_words_c(int N) { return (N + 1 + wpsi_epw_c(N) - 1) / wpsi_epw_c(N); }
+
+// ---- cross-lane helpers (wave64) -------------------------------------------------------------
+__device__ __forceinline__ double wave_bcast(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// value of lane-1 (lane 0 receives `carry`)
+__device__ __forceinline__ double lane_prev(double v, double carry, int lane)
+{
+    const double s = __shfl_up(v, 1);
+    return lane == 0 ? carry : s;
+}
+
+// inclusive scan of f_j(x) = max(x + a_j, b_j) over the lanes: on return f_j o ... o f_0 (x) =
+// max(x + a, b).  Identity element: (0, -inf).
+__device__ __forceinline__ void scan_maxplus(double &a, double &b, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double al = __shfl_up(a, d), bl = __shfl_up(b, d);
+        if (lane >= d) {
+            b = fmax(bl + a, b);
+            a = al + a;
+        }
+    }
+}
+
+// inclusive scan of f_j(x) = a_j * x + b_j.  Identity: (1, 0).
+__device__ __forceinline__ void scan_linear(double &a, double &b, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double al = __shfl_up(a, d), bl = __shfl_up(b, d);
+        if (lane >= d) {
+            b = __builtin_fma(a, bl, b);
+            a = al * a;
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// wave_engine.hip
+bool wave_supported(const HostModel &m, int64_t T, std::string *why);
+int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, int64_t block_req,
+                int64_t halo_req);
+int wave_set_model(WaveDev *r, int ch, const HostModel &m);
+void wave_destroy(WaveDev *r);
+int wave_prepare(WaveDev *r, const double *d_y, hipStream_t st);
+int wave_bind(WaveDev *r, const double *d_y, hipStream_t st);
+int64_t wave_stats_len(const WaveDev *r);
+int wave_diagnostics(WaveDev *r, hipStream_t st, int64_t diag[8]);
+int wave_profile_read(WaveDev *r, hipStream_t st, std::vector<std::string> &names,
+                      std::vector<double> &ms, std::vector<int64_t> &calls);
+// wave_viterbi.hip
+int wave_viterbi_sweep(WaveDev *r, const double *d_y, hipStream_t st);
+int wave_viterbi_post(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st);
+int wave_viterbi(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st);
+// wave_estep.hip
+int wave_estep(WaveDev *r, const double *d_y, double *d_stats, hipStream_t st);
+int wave_mstep(WaveDev *r, const double *d_stats, double *d_out, hipStream_t st);
+int wave_decode_estep(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll, double *d_stats,
+                      hipStream_t st);
+
+}  // namespace hmmsort

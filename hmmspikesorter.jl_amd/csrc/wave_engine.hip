@@ -1,0 +1,441 @@
+// Wave engine, part 1: geometry, workspace, model tables, the parallel pre-pass (ring scores).
+// Design notes: wave_common.h / DESIGN.md section 3.3.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "wave_common.h"
+
+namespace hmmsort {
+
+static inline int64_t wround_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+constexpr int64_t kWaveLdsMax = 160 * 1024;
+
+bool wave_supported(const HostModel &m, int64_t T, std::string *why)
+{
+    auto no = [&](const char *w) { if (why) *why = w; return false; };
+    if (!m.ring.valid) return no("transition list is not the no-overlap ring pattern");
+    if (m.ring.N > kRingMaxN) return no("more than 16 rings");
+    if (m.ring.L < 8) return no("rings shorter than 8 states");
+    if (T < 4 * (int64_t)m.ring.L || T < 512) return no("signal shorter than 4 ring lengths / 512 samples");
+    const int W = std::min(m.ring.L, 64);
+    const int64_t RB = wround_up(m.ring.L + W, 32);
+    if (2 * (int64_t)m.ring.N * RB * 8 > kWaveLdsMax) return no("delay lines exceed the LDS of one CU");
+    return true;
+}
+
+static int make_geometry(WaveGeom &g, int64_t T, int C, int N, int L, int64_t block_req, int64_t halo_req)
+{
+    g.T = T; g.C = C; g.N = N; g.L = L;
+    g.own_lo = 0; g.own_hi = T; g.first = 1; g.last = 1;
+    g.W = std::min(L, 64);
+    g.RB = (int)wround_up(L + g.W, 32);
+    // warm-up: four ring lengths, at least 256 samples; with chains of thousands of samples this is
+    // a few per cent of the sweep.  Every chain boundary is certified on device after the sweep
+    // (Viterbi: exact hand-off and re-sweep of the chain when the certificate fails).
+    int64_t H = halo_req > 0 ? halo_req : std::max<int64_t>(256, 4 * (int64_t)L);
+    H = std::max<int64_t>(H, L + 8);
+    const int64_t m = (H + g.W - 1) / g.W;
+    g.Hw = (int)(1 + m * g.W);
+    g.He = (int)(m * g.W);
+    // chain length: ~4 wavefronts per SIMD over all channels (1024 SIMDs), at least 2 warm-ups
+    int64_t B = block_req > 0 ? block_req : (T * C + 4095) / 4096;
+    B = std::max<int64_t>(B, std::max<int64_t>(2 * g.Hw, 512));
+    if (block_req > 0) B = std::max<int64_t>(block_req, std::max<int64_t>(g.Hw, L + 16));
+    B = wround_up(B, 64);
+    if (B > T) B = wround_up(T, 64);
+    for (;;) {  // every chain owns >= L samples (the per-chain normaliser needs a full ring window)
+        const int64_t nch = (T + B - 1) / B;
+        const int64_t nlast = T - (nch - 1) * B;
+        if (nch == 1 || nlast >= L) break;
+        B += 64;
+    }
+    HS_CHECK(B < (1 << 30), HMMSORT_EINVAL, "wave engine: chain too long");
+    g.B = (int)B;
+    g.nch = (int)((T + B - 1) / B);
+    int bits = 1;
+    while ((1 << bits) < N + 1) bits++;
+    g.EB = bits + 1; g.epw = 32 / g.EB; g.PW = (N + 1 + g.epw - 1) / g.epw;
+    g.Bb = 512; g.Hb = 128;
+    while (g.Hb < 2 * L + 64) g.Hb += 64;
+    if (g.Bb < 2 * g.Hb) g.Bb = 2 * g.Hb;
+    g.nseg = (T + g.Bb - 1) / g.Bb;
+    return HMMSORT_OK;
+}
+
+template <typename Tv>
+static int wmalloc(Tv **p, int64_t n, int64_t *bytes)
+{
+    if (hipMalloc((void **)p, (size_t)std::max<int64_t>(n, 1) * sizeof(Tv)) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("wave engine: hipMalloc of %.2f GB failed", n * sizeof(Tv) / 1e9);
+        *p = nullptr;
+        return HMMSORT_ENOMEM;
+    }
+    *bytes += n * (int64_t)sizeof(Tv);
+    return HMMSORT_OK;
+}
+
+int wave_set_model(WaveDev *r, int ch, const HostModel &m)
+{
+    const WaveGeom &g = r->g;
+    HS_CHECK(ch >= 0 && ch < g.C, HMMSORT_EINVAL, "wave set_model: channel %d outside 0..%d", ch, g.C - 1);
+    HS_CHECK(m.ring.valid && m.ring.N == g.N && m.ring.L == g.L && m.S == r->S, HMMSORT_EINVAL,
+             "wave set_model: model shape changed");
+    r->bound_y = nullptr;
+    r->ring[ch] = m.ring;
+    r->mean[ch] = m.mean;
+    r->sigma[ch] = m.sigma;
+    const int N = g.N, L = g.L;
+    const RingModel &R = m.ring;
+    WaveConst k;
+    memset(&k, 0, sizeof(k));
+    k.c00 = R.c00;
+    k.mean0 = m.mean[0];
+    k.den = 2.0 * (m.sigma * m.sigma);
+    k.A = -kLog2Pi - std::log(m.sigma);
+    double sc0 = R.c00;
+    for (int a = 0; a < N; a++) sc0 = std::max(sc0, R.cend[a]);
+    if (!std::isfinite(sc0)) sc0 = 0.0;
+    k.sc0 = sc0;
+    k.P00 = std::exp(R.c00 - sc0);
+    for (int a = 0; a < N; a++) {
+        k.c0[a] = R.c0[a];
+        k.cend[a] = R.cend[a];
+        k.PEND[a] = std::exp(R.cend[a] - sc0);
+        double sc = R.c0[a];                          // scale of the entries into ring a
+        for (int b = 0; b < N; b++)
+            if (b != a) sc = std::max(sc, R.cx[b * N + a]);
+        if (!std::isfinite(sc)) sc = 0.0;
+        sc = std::max(sc, kScFloor);
+        k.sc[a] = sc;
+        k.CP0[a] = std::exp(R.c0[a] - sc);
+        k.xishift[a] = R.c0[a] - sc;
+    }
+    for (int a = 0; a < N; a++)
+        for (int b = 0; b < N; b++) {
+            k.cx[a * N + b] = (a == b) ? -INFINITY : R.cx[a * N + b];
+            k.CPX[a * N + b] = (a == b) ? 0.0 : std::exp(R.cx[a * N + b] - k.sc[b]);
+        }
+    HS_HIP(hipMemcpy(r->d_cst + ch, &k, sizeof(k), hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(r->d_mean + (size_t)ch * m.S, m.mean.data(), m.S * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> cint((size_t)N * (L + 1), 0.0), msq((size_t)N * (L + 1), 0.0);
+    for (int a = 0; a < N; a++) {
+        double acc = 0.0, acc2 = 0.0;
+        for (int kk = 2; kk <= L; kk++) {
+            acc += R.cint[(size_t)a * L + (kk - 1)];  // lp((a,kk-1)->(a,kk))
+            cint[(size_t)a * (L + 1) + kk] = acc;
+        }
+        for (int kk = 1; kk <= L; kk++) {
+            const double mv = m.mean[1 + (size_t)a * L + (kk - 1)];
+            acc2 += mv * mv;
+            msq[(size_t)a * (L + 1) + kk] = acc2;
+        }
+    }
+    const size_t nt = (size_t)N * (L + 1);
+    HS_HIP(hipMemcpy(r->d_cint + ch * nt, cint.data(), nt * sizeof(double), hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(r->d_msq + ch * nt, msq.data(), nt * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> ctab;
+    ctab.push_back(R.c00);
+    ctab.insert(ctab.end(), R.c0.begin(), R.c0.end());
+    ctab.insert(ctab.end(), R.cend.begin(), R.cend.end());
+    ctab.insert(ctab.end(), R.cx.begin(), R.cx.end());
+    ctab.insert(ctab.end(), R.cint.begin(), R.cint.end());
+    HS_HIP(hipMemcpy(r->d_ctab + (size_t)ch * ctab.size(), ctab.data(), ctab.size() * sizeof(double),
+                     hipMemcpyHostToDevice));
+    if (ch == 0)
+        HS_HIP(hipMemcpy(r->d_states, m.states.data(), m.states.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    return HMMSORT_OK;
+}
+
+int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, int64_t block_req,
+                int64_t halo_req)
+{
+    HS_CHECK(!models.empty(), HMMSORT_EINVAL, "wave engine: no model");
+    const HostModel &m = models[0];
+    std::string why;
+    HS_CHECK(wave_supported(m, T, &why), HMMSORT_EUNSUP, "wave engine: %s", why.c_str());
+    const int C = (int)models.size();
+    WaveDev *r = new WaveDev();
+    int rc = make_geometry(r->g, T, C, m.ring.N, m.ring.L, block_req, halo_req);
+    if (rc) { delete r; return rc; }
+    r->S = m.S; r->K = m.K;
+    r->ring.resize(C); r->mean.resize(C); r->sigma.resize(C);
+    const WaveGeom &g = r->g;
+    const int64_t N = g.N, L = g.L, CT = (int64_t)C * T, nchT = (int64_t)C * g.nch;
+    r->nparts = 1024;
+    bool ok = true;
+    auto A = [&](auto **p, int64_t n) { if (ok && wmalloc(p, n, &r->bytes)) ok = false; };
+    A(&r->d_cst, C);
+    A(&r->d_mean, C * m.S);
+    A(&r->d_cint, C * N * (L + 1));
+    A(&r->d_msq, C * N * (L + 1));
+    A(&r->d_ctab, C * (1 + 2 * N + N * N + N * L));
+    A(&r->d_states, N * m.S);
+    A(&r->Rf, N * CT);
+    A(&r->virt, C * N * (L + 1));
+    A(&r->ysum, 2 * C);
+    A(&r->psi, (int64_t)g.PW * CT);
+    A(&r->vpre, nchT * (1 + N * L));
+    A(&r->vend, nchT * (1 + N * L));
+    A(&r->vfail, nchT + 8);
+    A(&r->bstate, C * g.nseg);
+    A(&r->redo, C * g.nseg + 8);
+    A(&r->final_state, C + 8);
+    A(&r->part, (int64_t)C * 4 * r->nparts);
+    A(&r->FA0, CT);
+    A(&r->FV, N * CT);
+    A(&r->FREF, CT);
+    A(&r->fpre, nchT * (1 + L * (N + 1)));
+    A(&r->bpre, nchT * (1 + L * (N + 1)));
+    A(&r->bown, nchT * (1 + L * (N + 1)));
+    A(&r->rho, N * CT);
+    A(&r->Zc, nchT);
+    A(&r->partS, nchT * (2 * N + 3));
+    r->gparts = (int)((T + 4095) / 4096);
+    A(&r->partG, (int64_t)C * r->gparts * 2 * N * L);
+    A(&r->yhead, C * (N * L + 2));
+    A(&r->extra, C * 3 * N * L);
+    A(&r->pp, C * m.S);
+    A(&r->diag, 8);
+    A(&r->dbg, 64);
+    if (!ok) { wave_destroy(r); return HMMSORT_ENOMEM; }
+    if (getenv("HMMSORT_POISON")) {  // test aid: NaN bit patterns in everything a kernel might read unwritten
+        (void)hipMemset(r->Rf, 0xFF, N * CT * 8);
+        (void)hipMemset(r->psi, 0xFF, (int64_t)g.PW * CT * 4);
+        (void)hipMemset(r->vpre, 0xFF, nchT * (1 + N * L) * 8);
+        (void)hipMemset(r->vend, 0xFF, nchT * (1 + N * L) * 8);
+        (void)hipMemset(r->FA0, 0xFF, CT * 8);
+        (void)hipMemset(r->FV, 0xFF, N * CT * 8);
+        (void)hipMemset(r->FREF, 0xFF, CT * 8);
+        (void)hipMemset(r->fpre, 0xFF, nchT * (1 + L * (N + 1)) * 8);
+        (void)hipMemset(r->bpre, 0xFF, nchT * (1 + L * (N + 1)) * 8);
+        (void)hipMemset(r->bown, 0xFF, nchT * (1 + L * (N + 1)) * 8);
+        (void)hipMemset(r->rho, 0xFF, N * CT * 8);
+        (void)hipMemset(r->Zc, 0xFF, nchT * 8);
+        (void)hipMemset(r->partS, 0xFF, nchT * (2 * N + 3) * 8);
+        (void)hipMemset(r->partG, 0xFF, (int64_t)C * r->gparts * 2 * N * L * 8);
+        (void)hipMemset(r->yhead, 0xFF, C * (N * L + 2) * 8);
+    }
+    if (hipMemset(r->diag, 0, 8 * sizeof(int64_t)) != hipSuccess ||
+        hipMemset(r->vfail, 0, (nchT + 8) * sizeof(int32_t)) != hipSuccess) {
+        wave_destroy(r);
+        return HMMSORT_EHIP;
+    }
+    for (int ch = 0; ch < C; ch++) {
+        const HostModel &mc = models[ch];
+        if (mc.S != m.S || mc.K != m.K || mc.N != m.N) {
+            set_error("wave engine: channel %d has a different model shape", ch);
+            wave_destroy(r);
+            return HMMSORT_EINVAL;
+        }
+        rc = wave_set_model(r, ch, mc);
+        if (rc) { wave_destroy(r); return rc; }
+    }
+    if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_b, hipEventDisableTiming) != hipSuccess) {
+        set_error("wave engine: could not create the internal stream/events");
+        wave_destroy(r);
+        return HMMSORT_EHIP;
+    }
+    *out = r;
+    return HMMSORT_OK;
+}
+
+void wave_destroy(WaveDev *r)
+{
+    if (!r) return;
+    void *ptrs[] = {r->d_cst, r->d_mean, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->Rf, r->virt, r->ysum,
+                    r->psi, r->vpre, r->vend, r->vfail, r->bstate, r->redo, r->final_state, r->part, r->FA0,
+                    r->FV, r->FREF, r->fpre, r->bpre, r->bown, r->rho, r->Zc, r->partS, r->partG, r->yhead,
+                    r->extra, r->pp, r->diag, r->dbg};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
+    if (r->ev_join) (void)hipEventDestroy(r->ev_join);
+    if (r->ev_a) (void)hipEventDestroy(r->ev_a);
+    if (r->ev_b) (void)hipEventDestroy(r->ev_b);
+    if (r->side) (void)hipStreamDestroy(r->side);
+    for (auto &e : r->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    delete r;
+}
+
+int wave_diagnostics(WaveDev *r, hipStream_t st, int64_t diag[8])
+{
+    HS_HIP(hipStreamSynchronize(st));
+    HS_HIP(hipMemcpy(diag, r->diag, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return HMMSORT_OK;
+}
+
+int64_t wave_stats_len(const WaveDev *r) { return 3 * (int64_t)r->g.N * r->g.L + r->g.N + 4; }
+
+// ------------------------------------------------------------------------------------------
+// pre-pass: ring scores for every onset time t' in [0, T) of every channel, natural layout
+//   Rf[ch][a][t'] = Cint[a][kmax] - (sum_k y^2 - 2 sum_k y*mean(a,k) + Msq[a][kmax]) / den,
+//   kmax = min(L, T - t')  (rings running off the end of the data are truncated: the reference's
+//   terminal conditions, viterbi.jl:90 / baumwelch.jl:80); y beyond the end counts as 0.
+// Block = 256 threads x 4 onsets; the y tile is staged in LDS once, means are wave-uniform.
+// Also accumulates sum y and sum y^2 per channel (magnitude of the reference's trellis, for the
+// near-tie threshold of the Viterbi sweep).
+// ------------------------------------------------------------------------------------------
+constexpr int kPreTile = 1024;
+
+template <int N>
+__global__ __launch_bounds__(256) void kw_prepass(WaveGeom g, const WaveConst *__restrict__ cst,
+                                                  const double *__restrict__ y,
+                                                  const double *__restrict__ mean,
+                                                  const double *__restrict__ cint,
+                                                  const double *__restrict__ msq,
+                                                  double *__restrict__ Rf, double *__restrict__ ysum)
+{
+    extern __shared__ double ly[];  // kPreTile + L
+    __shared__ double red[8];
+    const int ch = blockIdx.y, L = g.L, S = 1 + N * L;
+    const int64_t T = g.T, t0 = (int64_t)blockIdx.x * kPreTile;
+    const double *yc = y + (int64_t)ch * T;
+    const double *mc = mean + (int64_t)ch * S;
+    for (int i = threadIdx.x; i < kPreTile + L; i += 256) {
+        const int64_t t = t0 + i;
+        const double v = yc[t < T ? t : T - 1];
+        ly[i] = t < T ? v : 0.0;
+    }
+    __syncthreads();
+    double dot[4][N], ysq[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        ysq[r] = 0.0;
+#pragma unroll
+        for (int a = 0; a < N; a++) dot[r][a] = 0.0;
+    }
+    for (int k = 0; k < L; k++) {
+        double mv[N];
+#pragma unroll
+        for (int a = 0; a < N; a++) mv[a] = mc[1 + a * L + k];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double yv = ly[threadIdx.x + 256 * r + k];
+            ysq[r] = __builtin_fma(yv, yv, ysq[r]);
+#pragma unroll
+            for (int a = 0; a < N; a++) dot[r][a] = __builtin_fma(yv, mv[a], dot[r][a]);
+        }
+    }
+    const double den = cst[ch].den;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int64_t t = t0 + threadIdx.x + 256 * r;
+        if (t < T) {
+            const int64_t rem = T - t;
+            const int kmax = rem < L ? (int)rem : L;
+#pragma unroll
+            for (int a = 0; a < N; a++) {
+                const double ss = (ysq[r] - 2.0 * dot[r][a]) + msq[((int64_t)ch * N + a) * (L + 1) + kmax];
+                Rf[((int64_t)ch * N + a) * T + t] = cint[((int64_t)ch * N + a) * (L + 1) + kmax] - ss / den;
+            }
+            const double yv = ly[threadIdx.x + 256 * r];
+            s1 += yv; s2 = __builtin_fma(yv, yv, s2);
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s1; red[4 + (threadIdx.x >> 6)] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&ysum[2 * ch], (red[0] + red[1]) + (red[2] + red[3]));
+        atomicAdd(&ysum[2 * ch + 1], (red[4] + red[5]) + (red[6] + red[7]));
+    }
+}
+
+// virtual onsets t' = -j, j = 1..L-1: rings already running at the first sample (the reference's
+// first column is "emission only" for every state: viterbi.jl:55-62, baumwelch.jl:36).  Their score
+// covers phases k = 1+j..L on samples 0..L-1-j.  V[ch][a][j]; V[.][.][L] = -inf ("no such onset").
+__global__ void kw_virtual(WaveGeom g, const WaveConst *__restrict__ cst, const double *__restrict__ y,
+                           const double *__restrict__ mean, const double *__restrict__ cint,
+                           double *__restrict__ virt)
+{
+    const int L = g.L, N = g.N, ch = blockIdx.x, S = 1 + N * L;
+    const double *yc = y + (int64_t)ch * g.T, *mc = mean + (int64_t)ch * S;
+    const double *ci = cint + (int64_t)ch * N * (L + 1);
+    const double den = cst[ch].den, A = cst[ch].A;
+    for (int i = threadIdx.x; i < N * L; i += blockDim.x) {
+        const int a = i / L, j = i % L + 1;  // j = 1..L
+        double v;
+        if (j == L) {
+            v = -INFINITY;
+        } else if (j == L - 1) {
+            // A ring in its LAST phase at the first sample: one emission term.  Template tails are
+            // ~1e-16 (sin(3*pi)), so these N candidates tie to the last bit in the reference, whose
+            // first column is funcl = A - d*d/den (viterbi.jl:55-62); round exactly like it, then take
+            // A out again, so that equal reference values stay equal here (lowest ring wins the tie).
+            const double d = yc[0] - mc[1 + a * L + (L - 1)];
+            v = (A - (d * d) / den) - A;
+        } else {
+            double acc = 0.0;
+            for (int k = 1 + j; k <= L; k++) {
+                const double d = yc[k - 1 - j] - mc[1 + a * L + (k - 1)];
+                acc += d * d;
+            }
+            v = (ci[a * (L + 1) + L] - ci[a * (L + 1) + (1 + j)]) - acc / den;
+        }
+        virt[((int64_t)ch * N + a) * (L + 1) + j] = v;
+    }
+}
+
+int wave_prepare(WaveDev *r, const double *d_y, hipStream_t st)
+{
+    if (r->bound_y == d_y) return HMMSORT_OK;
+    r->bound_y = nullptr;
+    const WaveGeom &g = r->g;
+    HS_HIP(hipMemsetAsync(r->ysum, 0, 2 * g.C * sizeof(double), st));
+    int rc = dispatch_N(g.N, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        WPROF(r, "kw_prepass", st);
+        hipLaunchKernelGGL((kw_prepass<N>), dim3((unsigned)((g.T + kPreTile - 1) / kPreTile), g.C), dim3(256),
+                           (size_t)(kPreTile + g.L) * sizeof(double), st, g, r->d_cst, d_y, r->d_mean, r->d_cint,
+                           r->d_msq, r->Rf, r->ysum);
+        HS_HIP(hipGetLastError());
+        return HMMSORT_OK;
+    });
+    if (rc) return rc;
+    { WPROF(r, "kw_virtual", st);
+      hipLaunchKernelGGL(kw_virtual, dim3(g.C), dim3(256), 0, st, g, r->d_cst, d_y, r->d_mean, r->d_cint, r->virt); }
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+int wave_bind(WaveDev *r, const double *d_y, hipStream_t st)
+{
+    r->bound_y = nullptr;
+    int rc = wave_prepare(r, d_y, st);
+    if (rc) return rc;
+    r->bound_y = d_y;
+    return HMMSORT_OK;
+}
+
+int wave_profile_read(WaveDev *r, hipStream_t st, std::vector<std::string> &names,
+                      std::vector<double> &ms, std::vector<int64_t> &calls)
+{
+    HS_HIP(hipStreamSynchronize(st));
+    if (r->side) HS_HIP(hipStreamSynchronize(r->side));
+    for (auto &e : r->prof) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) { (void)hipGetLastError(); t = 0.f; }
+        size_t i = 0;
+        for (; i < names.size(); i++)
+            if (names[i] == e.name) break;
+        if (i == names.size()) { names.push_back(e.name); ms.push_back(0.0); calls.push_back(0); }
+        ms[i] += t;
+        calls[i] += 1;
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    r->prof.clear();
+    return HMMSORT_OK;
+}
+
+}  // namespace hmmsort

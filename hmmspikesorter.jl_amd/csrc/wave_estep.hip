@@ -1,0 +1,916 @@
+// Wave engine, part 3: one Baum-Welch step = forward -> backward -> update
+// (reference src/baumwelch.jl:25-51, :73-98, :205-309, :362-370) without ever materialising alpha,
+// beta, gamma or xi, one wavefront per chain.  Specification: tests/wave_model.py (fwd_chain,
+// bwd_chain, estep), checked against the CPU oracle.
+//
+// Scaled representation (no logarithm inside the sweeps, N+1 exponentials per sample):
+//   exp(la0(t)) = x_t exp(M_t)          silent forward value; M_t = max-plus envelope (lane scan),
+//                                       x_t = al_t x_{t-1} + be_t (linear lane scan)
+//   onset mass of ring a at t:          lp_a(t) = fref_t + sc_a + log fv_a(t) + R_a(t)
+//   exp(lb0(t)) = xb_t exp(Mb_t)        silent backward value
+//   beta of ring a's last state at t:   Yn_a(t) = Mb_t + log yn_a(t)
+// sc_a = scale of the entry transitions into ring a (floored at -700): entry probabilities far below
+// the double range stay in exponents, so the re-estimated lp of a vanishing template is finite as in
+// the reference's log-domain folds (baumwelch.jl:254-261).
+// The backward sweep is fused with update(): at step t it has the posteriors
+//   gamma_t(silent) = xb_t g,                      g  = exp(la0(t) + Mb_t - z)
+//   xi_a(t+1)       = CP0_a w_a g                  (silent -> ring a), w_a = yn-weighted start term
+//   rho_a(t+1)      = fv_a(t+1) w_a g2,            g2 = exp(fref_{t+1} + Mb_t - z)
+// (rho_a(t') = posterior that ring a started at t' = gamma of all L states of that ring pass), z =
+// the chain's normaliser log sum_j alpha(j) beta(j), evaluated once where the sweep enters the
+// chain's own samples.  The M-step sums are posterior-weighted spike-triggered sums of y (kw_gsum*).
+#include <cmath>
+#include <type_traits>
+
+#include "fastmath.h"
+#include "wave_common.h"
+
+namespace hmmsort {
+
+constexpr double kLn2 = 6.93147180559945286227e-01;
+
+__device__ __forceinline__ double scale_of(double v, double s)  // s + log2-exponent of v, -inf for v <= 0
+{
+    return v > 0.0 ? s + (double)ilogb(v) * kLn2 : -INFINITY;
+}
+
+template <int N>
+struct FIn {
+    double y;
+    double R[N];
+};
+
+// ------------------------------------------------------------------------------------------
+// forward chains (baumwelch.jl:25-51)
+// ------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(64) void kw_fwd(WaveGeom g, const WaveConst *__restrict__ cst,
+                                             const double *__restrict__ y, const double *__restrict__ Rf,
+                                             const double *__restrict__ virt, double *__restrict__ FA0,
+                                             double *__restrict__ FV, double *__restrict__ FREF,
+                                             double *__restrict__ fpre)
+{
+    extern __shared__ double lds[];
+    const int L = g.L, W = g.W, RB = g.RB, B = g.B;
+    double *DLv = lds, *DLs = lds + N * RB;  // onset t': (v_a, s_a), X_a = s_a + log v_a
+    const int lane = threadIdx.x;
+    const int cg = blockIdx.x, ch = cg / g.nch, c = cg % g.nch;
+    const WaveConst &K = cst[ch];
+    const int64_t T = g.T;
+    const int64_t tc = (int64_t)c * B;
+    const int nc = (int)((T - tc) < B ? (T - tc) : B);
+    const int64_t tend = tc + nc;
+    const double *yc = y + (int64_t)ch * T;
+    const double *Rc = Rf + (int64_t)ch * N * T;
+    double *FAc = FA0 + (int64_t)ch * T, *FRc = FREF + (int64_t)ch * T, *FVc = FV + (int64_t)ch * N * T;
+    const int64_t FR = 1 + (int64_t)L * (N + 1);
+    double *rec = fpre + cg * FR;
+    const double einv = fexp(-K.sc0);
+
+    for (int i = lane; i < 2 * N * RB; i += 64) lds[i] = 0.0;
+    __syncthreads();
+    int64_t tinit;
+    double M, x = 1.0;
+    if (c == 0) {  // baumwelch.jl:36: first column = emission only, every state
+        tinit = 0;
+        for (int i = lane; i < N * L; i += 64) {
+            const int a = i / L, j = i % L + 1;
+            if (j < L) {
+                DLv[a * RB + (L - j)] = 1.0;
+                DLs[a * RB + (L - j)] = virt[((int64_t)ch * N + a) * (L + 1) + j];
+            }
+        }
+        const double d0 = yc[0] - K.mean0;
+        M = -((d0 * d0) / K.den);
+        if (lane < N) {
+            const double f0 = fexp(-K.sc[lane]);
+            DLv[lane * RB + L] = f0;
+            DLs[lane * RB + L] = K.sc[lane] + Rc[(int64_t)lane * T];
+            FVc[(int64_t)lane * T] = f0;
+        }
+        if (lane == 0) { FAc[0] = M; FRc[0] = 0.0; }
+    } else {
+        tinit = tc - g.Hw;
+        M = 0.0;
+    }
+    __syncthreads();
+
+    const int n_total = (int)(tend - 1 - tinit);
+    auto load = [&](FIn<N> &d, int off) {
+        const int nact = n_total - off < W ? n_total - off : W;
+        int64_t t = tinit + 1 + off + (lane < nact ? lane : 0);
+        t = t < T ? t : T - 1;
+        d.y = yc[t];
+#pragma unroll
+        for (int a = 0; a < N; a++) d.R[a] = Rc[(int64_t)a * T + t];
+    };
+    int rs = (1 + lane) % RB, ws = (L + 1 + lane) % RB;
+    auto run = [&](const FIn<N> &d, int off) {
+        const int nact = n_total - off < W ? n_total - off : W;
+        const bool live = lane < nact;
+        const int64_t t = tinit + 1 + off + lane;
+        double v[N], E[N + 1];
+        double e = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            v[a] = live ? DLv[a * RB + rs] : 0.0;
+            E[a] = DLs[a * RB + rs] + K.sc0;            // scale of the exit of ring a
+            e = fmax(e, scale_of(v[a], E[a]));
+        }
+        const double dd = d.y - K.mean0;
+        const double q0 = -((dd * dd) / K.den);
+        double sa = live ? K.sc0 + q0 : 0.0;
+        double sb = live ? e + q0 : -INFINITY;
+        scan_maxplus(sa, sb, lane);
+        const double Mt = fmax(M + sa, sb);
+        const double Mprev = lane_prev(Mt, M, lane);
+        const double ref = Mt - q0;
+        E[N] = (Mprev + K.sc0) - ref;
+#pragma unroll
+        for (int a = 0; a < N; a++) E[a] = v[a] > 0.0 ? fmin(E[a] - ref, 700.0) : -INFINITY;  // 0 * exp(big) = NaN
+        fexp_n<N + 1>(E);
+        const double E0 = E[N];
+        double Ea[N];
+        double al = E0 * K.P00, be = 0.0;
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            Ea[a] = v[a] * E[a];
+            be = __builtin_fma(Ea[a], K.PEND[a], be);
+        }
+        al = live ? al : 1.0;
+        be = live ? be : 0.0;
+        scan_linear(al, be, lane);
+        const double xt = __builtin_fma(al, x, be);
+        const double xprev = lane_prev(xt, x, lane);
+        const double base = (xprev * E0) * einv;          // exp(la0(t-1) - ref)
+        double u[N];
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            double su = base * K.CP0[a];
+#pragma unroll
+            for (int b = 0; b < N; b++)
+                if (b != a) su = __builtin_fma(Ea[b] * einv, K.CPX[b * N + a], su);
+            u[a] = su;
+        }
+        if (live) {
+#pragma unroll
+            for (int a = 0; a < N; a++) {
+                DLv[a * RB + ws] = u[a];
+                DLs[a * RB + ws] = (ref + K.sc[a]) + d.R[a];
+            }
+            const double la0 = Mt + flog(xt);
+            if (t >= tc) {
+                FAc[t] = la0;
+                FRc[t] = ref;
+#pragma unroll
+                for (int a = 0; a < N; a++) FVc[(int64_t)a * T + t] = u[a];
+            } else if (t >= tc - L) {  // warm-up copy of the boundary state (certificate)
+                const int64_t jj = t - (tc - L);
+#pragma unroll
+                for (int a = 0; a < N; a++) rec[1 + jj * (N + 1) + a] = u[a];
+                rec[1 + jj * (N + 1) + N] = ref;
+                if (t == tc - 1) rec[0] = la0;
+            }
+        }
+        x = wave_bcast(xt, 63);
+        M = wave_bcast(Mt, 63);
+        const int ee = x > 0.0 ? ilogb(x) : 0;
+        if (ee >= 32 || ee <= -32) { x = ldexp(x, -ee); M += (double)ee * kLn2; }
+        rs += W; rs = rs >= RB ? rs - RB : rs;
+        ws += W; ws = ws >= RB ? ws - RB : ws;
+    };
+    FIn<N> bufA, bufB;
+    load(bufA, 0);
+    for (int off = 0; off < n_total; off += 2 * W) {
+        load(bufB, off + W);
+        run(bufA, off);
+        if (off + W < n_total) {
+            load(bufA, off + 2 * W);
+            run(bufB, off + W);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward chains (baumwelch.jl:73-98) + posteriors of update() (:205-309)
+// Chain c starts at te-1, te = min(tend + He, T), with beta = 0 for every state (the reference's
+// terminal condition when te is the end of the data, an arbitrary warm-up start otherwise), sweeps
+// down to tstar = tend-1 (warm-up), fixes the normaliser z there, and sweeps its own samples down to
+// tc-1 (the step at tc-1 yields the posteriors of the onsets at tc).
+// Delay line: Yn(tau) at slot (te-1-tau) mod RB; slots never written hold (1, 0) = "beta = 0".
+// ------------------------------------------------------------------------------------------
+template <int N>
+struct BIn {
+    double y1, y0;    // y(t+1), y(t)
+    double R[N];      // R_a(t+1)
+    double fv[N];     // fv_a(t+1)
+    double fref, la0; // fref(t+1), la0(t)
+};
+
+template <int N>
+__global__ __launch_bounds__(64) void kw_bwd(WaveGeom g, const WaveConst *__restrict__ cst,
+                                             const double *__restrict__ y, const double *__restrict__ Rf,
+                                             const double *__restrict__ FA0, const double *__restrict__ FV,
+                                             const double *__restrict__ FREF, const double *__restrict__ fpre,
+                                             double *__restrict__ rho, double *__restrict__ partS,
+                                             double *__restrict__ Zc, double *__restrict__ bpre,
+                                             double *__restrict__ bown, double *__restrict__ yhead)
+{
+    extern __shared__ double lds[];
+    const int L = g.L, W = g.W, RB = g.RB, B = g.B;
+    double *DLv = lds, *DLs = lds + N * RB;
+    const int lane = threadIdx.x;
+    const int cg = blockIdx.x, ch = cg / g.nch, c = cg % g.nch;
+    const WaveConst &K = cst[ch];
+    const int64_t T = g.T;
+    const int64_t tc = (int64_t)c * B;
+    const int nc = (int)((T - tc) < B ? (T - tc) : B);
+    const int64_t tend = tc + nc, tstar = tend - 1;
+    const int64_t te = (tend + g.He) < T ? (tend + g.He) : T;
+    const double *yc = y + (int64_t)ch * T;
+    const double *Rc = Rf + (int64_t)ch * N * T;
+    const double *FAc = FA0 + (int64_t)ch * T, *FRc = FREF + (int64_t)ch * T, *FVc = FV + (int64_t)ch * N * T;
+    double *rhoc = rho + (int64_t)ch * N * T;
+    const int64_t FR = 1 + (int64_t)L * (N + 1);
+    const double la0pre = c > 0 ? fpre[cg * FR] : 0.0;
+    double *recp = bpre + cg * FR, *reco = bown + cg * FR;
+    double *yh = yhead + (int64_t)ch * (N * L + 2);
+
+    for (int i = lane; i < N * RB; i += 64) DLv[i] = 1.0;
+    for (int i = lane; i < RB; i += 64) DLs[i] = 0.0;
+    __syncthreads();
+
+    double Mb = 0.0, xb = 1.0, z = 0.0;
+    double sx[N], ra[N], s_all = 0.0, s_m = 0.0, s_y2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < N; a++) { sx[a] = 0.0; ra[a] = 0.0; }
+
+    const int n_warm = (int)(te - tend);                 // steps t = te-2 .. tstar
+    const int n_total = n_warm + nc;                     // ... then tstar-1 .. tc-1
+    // super-step schedule: the first warm-up step may be partial so that the warm-up ends exactly at
+    // tstar; then full steps; the last owned step may be partial
+    auto width = [&](int done) {
+        if (done < n_warm) { const int r = (n_warm - done) % W; return r ? r : W; }
+        return n_total - done < W ? n_total - done : W;
+    };
+    auto load = [&](BIn<N> &d, int done) {
+        const int nact = done < n_total ? width(done) : 0;
+        int64_t t = te - 2 - done - (lane < nact ? lane : 0);
+        t = t < -1 ? -1 : t;
+        const int64_t t1 = t + 1 < T ? t + 1 : T - 1;
+        const int64_t tz = t < 0 ? 0 : t;
+        d.y1 = yc[t1];
+        d.y0 = yc[tz];
+        d.fref = FRc[t1];
+        d.la0 = FAc[tz];
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            d.R[a] = Rc[(int64_t)a * T + t1];
+            d.fv[a] = FVc[(int64_t)a * T + t1];
+        }
+    };
+    auto run = [&](const BIn<N> &d, int done) {
+        const int nact = width(done);
+        const bool live = lane < nact;
+        const int i = done + 1 + lane;                   // step index: t = te-1-i
+        const int64_t t = te - 1 - i;
+        const bool owned = done >= n_warm;               // wave-uniform
+        int ws = (done + 1) % RB + lane;                 // (done+1) % RB is wave-uniform
+        ws = ws >= RB ? ws - RB : ws;
+        int rs = ws - L;
+        rs = rs < 0 ? rs + RB : rs;
+        double vb[N], E[N + 1];
+        const double sbv = DLs[rs];
+        double e = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            vb[a] = live ? DLv[a * RB + rs] : 0.0;
+            E[a] = (sbv + d.R[a]) + K.sc[a];             // sw_a
+            e = fmax(e, scale_of(vb[a], E[a]));
+        }
+        const double dd = d.y1 - K.mean0;
+        const double q1 = -((dd * dd) / K.den);
+        double sa = live ? q1 + K.sc0 : 0.0;
+        double sb = live ? e : -INFINITY;
+        scan_maxplus(sa, sb, lane);
+        const double Mt = fmax(Mb + sa, sb);
+        const double Mnext = lane_prev(Mt, Mb, lane);
+        E[N] = ((Mnext + q1) + K.sc0) - Mt;
+#pragma unroll
+        for (int a = 0; a < N; a++) E[a] = vb[a] > 0.0 ? fmin(E[a] - Mt, 700.0) : -INFINITY;
+        fexp_n<N + 1>(E);
+        const double E0 = E[N];
+        double wa[N];
+        double al = E0 * K.P00, be = 0.0;
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            wa[a] = vb[a] * E[a];
+            be = __builtin_fma(wa[a], K.CP0[a], be);
+        }
+        al = live ? al : 1.0;
+        be = live ? be : 0.0;
+        scan_linear(al, be, lane);
+        const double xt = __builtin_fma(al, xb, be);
+        const double xnext = lane_prev(xt, xb, lane);
+        const double base = xnext * E0;
+        double yn[N];
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            double su = base * K.PEND[a];
+#pragma unroll
+            for (int b = 0; b < N; b++)
+                if (b != a) su = __builtin_fma(wa[b], K.CPX[a * N + b], su);
+            yn[a] = su;
+        }
+        if (live) {
+#pragma unroll
+            for (int a = 0; a < N; a++) DLv[a * RB + ws] = yn[a];
+            DLs[ws] = Mt;
+            // boundary records for the certificate: values at the first L samples of the next
+            // chain (warm-up) / of this chain (own sweep)
+            double *rr = nullptr;
+            int64_t jj = 0;
+            if (!owned && t >= tend && t < tend + L) { rr = recp; jj = t - tend; }
+            if (owned && t >= tc && t < tc + L) { rr = reco; jj = t - tc; }
+            if (rr) {
+#pragma unroll
+                for (int a = 0; a < N; a++) rr[1 + jj * (N + 1) + a] = yn[a];
+                rr[1 + jj * (N + 1) + N] = Mt;
+                if (jj == 0) rr[0] = Mt + flog(xt);
+            }
+        }
+        if (owned) {
+            const double la = t >= tc ? d.la0 : la0pre;
+            double gg[2] = {fmin((la + Mt) - z, 700.0), fmin((d.fref + Mt) - z, 700.0)};
+            fexp_n<2>(gg);
+            const int64_t t1 = t + 1;
+            if (live && t >= tc && t >= g.own_lo && t < g.own_hi) {
+                const double ga = xt * gg[0];                    // gamma_t(silent)
+                s_all += ga;                                     // baumwelch.jl:303 qq
+                if (!g.last || t < T - 1) s_m += ga;             // :257 bb, t = 1..T-1 of the recording
+                s_y2 = __builtin_fma(ga, d.y0 * d.y0, s_y2);     // :302 with the new silent mean (= 0)
+            }
+            const bool own1 = live && t1 >= g.own_lo && t1 < g.own_hi;
+            const bool bulk = !(g.last && t1 > T - L);           // truncated rings: summed per phase in kw_edges
+#pragma unroll
+            for (int a = 0; a < N; a++) {
+                const double rv = own1 ? (d.fv[a] * wa[a]) * gg[1] : 0.0;
+                if (live) rhoc[(int64_t)a * T + t1] = rv;
+                ra[a] += bulk ? rv : 0.0;
+                sx[a] += (own1 && t >= 0) ? wa[a] * gg[0] : 0.0;  // xi'_a(t+1): silent(t) -> (a,1)(t+1), :240
+            }
+            if (c == 0 && t < L && live && t >= 0) {             // head of the recording: virtual onsets, pp
+                double lg[N + 1];
+#pragma unroll
+                for (int a = 0; a < N; a++) lg[a] = yn[a];
+                lg[N] = xt;
+                flog_n<N + 1>(lg);
+#pragma unroll
+                for (int a = 0; a < N; a++) yh[a * L + t] = Mt + lg[a];
+                if (t == 0) yh[N * L] = Mt + lg[N];
+            }
+        }
+        xb = wave_bcast(xt, 63);
+        Mb = wave_bcast(Mt, 63);
+        const int ee = xb > 0.0 ? ilogb(xb) : 0;
+        if (ee >= 32 || ee <= -32) { xb = ldexp(xb, -ee); Mb += (double)ee * kLn2; }
+    };
+    // normaliser at tstar (all lanes return the same z) and gamma_tstar(silent)
+    auto znorm = [&]() {
+        __syncthreads();
+        const double la = FAc[tstar];
+        double zmax = la + Mb + (double)ilogb(xb) * kLn2;
+        double sc_[N], mant[N];   // one onset per lane and pass
+        for (int i0 = 0; i0 < L; i0 += 64) {
+            const int i = i0 + lane;
+            const bool on = i < L;
+            const int64_t tp = tstar - (on ? i : 0);
+            int slot = (int)((te - 1 - (tp + L - 1)) % RB);
+            slot = slot < 0 ? slot + RB : slot;
+            const double sbv = DLs[slot], fr = FRc[tp];
+#pragma unroll
+            for (int a = 0; a < N; a++) {
+                const double m = FVc[(int64_t)a * T + tp] * DLv[a * RB + slot];
+                const double s = ((fr + K.sc[a]) + Rc[(int64_t)a * T + tp]) + sbv;
+                if (on) zmax = fmax(zmax, scale_of(m, s));
+            }
+        }
+        zmax = wave_max(zmax);
+        double zs = 0.0;
+        for (int i0 = 0; i0 < L; i0 += 64) {
+            const int i = i0 + lane;
+            const bool on = i < L;
+            const int64_t tp = tstar - (on ? i : 0);
+            int slot = (int)((te - 1 - (tp + L - 1)) % RB);
+            slot = slot < 0 ? slot + RB : slot;
+            const double sbv = DLs[slot], fr = FRc[tp];
+#pragma unroll
+            for (int a = 0; a < N; a++) {
+                mant[a] = FVc[(int64_t)a * T + tp] * DLv[a * RB + slot];
+                sc_[a] = mant[a] > 0.0 ? fmin((((fr + K.sc[a]) + Rc[(int64_t)a * T + tp]) + sbv) - zmax, 700.0) : -INFINITY;
+            }
+            fexp_n<N>(sc_);
+#pragma unroll
+            for (int a = 0; a < N; a++) zs += on ? mant[a] * sc_[a] : 0.0;
+        }
+        zs = wave_sum(zs);
+        zs += xb * fexp((la + Mb) - zmax);
+        z = zmax + flog(zs);
+        if (lane == 0) {
+            Zc[cg] = z;
+            if (tstar >= g.own_lo && tstar < g.own_hi) {
+                const double ga = xb * fexp((la + Mb) - z);
+                s_all += ga;
+                if (!g.last || tstar < T - 1) s_m += ga;
+                const double yv = yc[tstar];
+                s_y2 = __builtin_fma(ga, yv * yv, s_y2);
+            }
+            if (c == 0 && tstar == 0) yh[N * L] = Mb + flog(xb);
+        }
+        __syncthreads();
+    };
+
+    BIn<N> bufA, bufB;
+    int done = 0;
+    if (n_warm == 0) znorm();
+    load(bufA, 0);
+    while (done < n_total) {
+        const int w1 = width(done);
+        load(bufB, done + w1);
+        run(bufA, done);
+        done += w1;
+        if (done == n_warm) znorm();
+        if (done >= n_total) break;
+        const int w2 = width(done);
+        load(bufA, done + w2);
+        run(bufB, done);
+        done += w2;
+        if (done == n_warm) znorm();
+    }
+    // per-chain partial sums -> partS[cg][2N+3] = sx | ra | s_all s_m s_y2
+    double *ps = partS + (int64_t)cg * (2 * N + 3);
+#pragma unroll
+    for (int a = 0; a < N; a++) {
+        const double v1 = wave_sum(sx[a]), v2 = wave_sum(ra[a]);
+        if (lane == 0) { ps[a] = v1; ps[N + a] = v2; }
+    }
+    {
+        const double v1 = wave_sum(s_all), v2 = wave_sum(s_m), v3 = wave_sum(s_y2);
+        if (lane == 0) { ps[2 * N] = v1; ps[2 * N + 1] = v2; ps[2 * N + 2] = v3; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Boundary certificate of the warm-ups (diag[3..6]).  One wavefront per boundary between chains
+// c-1 and c.  Forward: the state chain c reached at the end of its warm-up (la0 at tc-1 and the L
+// onsets still inside their rings) against what chain c-1 computed for the same quantities;
+// backward: the state chain c-1 reached at tc coming down from its warm-up (lb0 at tc and the
+// ring-end betas Yn_a(tc..tc+L-2)) against chain c's own.  Both pairs may differ by a frame constant
+// D, taken at the entry with the largest posterior weight; the error is the posterior-weighted
+// relative mismatch sum_e w_e |exp((x_e - x'_e) - D) - 1| (tolerance 1e-9).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void kw_fb_check(WaveGeom g, double tol, const double *__restrict__ FA0,
+                                                  const double *__restrict__ FV, const double *__restrict__ FREF,
+                                                  const double *__restrict__ fpre, const double *__restrict__ bpre,
+                                                  const double *__restrict__ bown, const double *__restrict__ rho,
+                                                  int64_t *__restrict__ diag, double *__restrict__ dbg)
+{
+    const int lane = threadIdx.x;
+    const int cg = blockIdx.x, ch = cg / g.nch, c = cg % g.nch;
+    if (c == 0) return;
+    const int N = g.N, L = g.L;
+    const int64_t T = g.T, tc = (int64_t)c * g.B;
+    const int64_t FR = 1 + (int64_t)L * (N + 1);
+    const double *FAc = FA0 + (int64_t)ch * T, *FRc = FREF + (int64_t)ch * T, *FVc = FV + (int64_t)ch * N * T;
+    const double *rhoc = rho + (int64_t)ch * N * T;
+    for (int dir = 0; dir < 2; dir++) {
+        const int ne = dir == 0 ? L : L - 1;
+        // entry (a, e): forward onset t' = tc-1-e; backward ring-end beta at tc+e (onset tc+e-L+1)
+        auto weight = [&](int a, int e) {
+            const int64_t tp = dir == 0 ? tc - 1 - e : tc + e - L + 1;
+            return tp >= 0 ? rhoc[(int64_t)a * T + tp] : 0.0;
+        };
+        auto diff = [&](int a, int e) {
+            double hv, hs, mv, ms;
+            if (dir == 0) {
+                const int64_t tp = tc - 1 - e, jj = tp - (tc - L);
+                hv = fpre[cg * FR + 1 + jj * (N + 1) + a]; hs = fpre[cg * FR + 1 + jj * (N + 1) + N];
+                mv = FVc[(int64_t)a * T + tp]; ms = FRc[tp];
+            } else {
+                hv = bpre[(cg - 1) * FR + 1 + (int64_t)e * (N + 1) + a]; hs = bpre[(cg - 1) * FR + 1 + (int64_t)e * (N + 1) + N];
+                mv = bown[cg * FR + 1 + (int64_t)e * (N + 1) + a]; ms = bown[cg * FR + 1 + (int64_t)e * (N + 1) + N];
+            }
+            if (hv == mv && hs == ms) return 0.0;
+            if (!(hv > 0.0) && !(mv > 0.0)) return 0.0;      // both impossible
+            return (hs - ms) + (flog(hv) - flog(mv));
+        };
+        // silent entry: weight = 1 - ring mass at the boundary sample
+        double ringmass = 0.0;
+        const int64_t tb = dir == 0 ? tc - 1 : tc;
+        for (int idx = lane; idx < N * L; idx += 64) {
+            const int a = idx / L, k = idx % L;
+            const int64_t tp = tb - k;
+            if (tp >= 0) ringmass += rhoc[(int64_t)a * T + tp];
+        }
+        ringmass = wave_sum(ringmass);
+        const double w0 = fmax(1.0 - ringmass, 0.0);
+        const double d0 = dir == 0 ? fpre[cg * FR] - FAc[tc - 1] : bpre[(cg - 1) * FR] - bown[cg * FR];
+        double wb = lane == 0 ? w0 : -1.0, db = d0;
+        int bi = -1;
+        for (int idx = lane; idx < N * ne; idx += 64) {
+            const int a = idx / ne, e = idx % ne;
+            const double w = weight(a, e);
+            if (w > wb) { wb = w; db = diff(a, e); bi = idx; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ow = __shfl_xor(wb, o), od = __shfl_xor(db, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ow > wb) { wb = ow; db = od; bi = oi; }
+        }
+        bi = __builtin_amdgcn_readfirstlane(bi);
+        const double D = wave_bcast(db, 0);
+        double err = lane == 0 ? w0 * fabs(fexp(fmin(d0 - D, 700.0)) - 1.0) : 0.0;
+        for (int idx = lane; idx < N * ne; idx += 64) {
+            const int a = idx / ne, e = idx % ne;
+            const double w = weight(a, e);
+            if (w > 0.0) err += w * fabs(fexp(fmin(diff(a, e) - D, 700.0)) - 1.0);
+        }
+        err = wave_sum(err);
+        if (lane == 0) {
+            if (!(err <= tol) && dbg && atomicAdd((unsigned long long *)&diag[3 + 2 * dir], 0ull) == 0ull) {
+                dbg[0] = cg; dbg[1] = dir; dbg[2] = D; dbg[3] = w0; dbg[4] = d0; dbg[5] = err; dbg[6] = ringmass;
+                dbg[7] = wb; dbg[8] = bi; dbg[9] = tc; dbg[10] = ne;
+            }
+            if (!(err <= tol)) atomicAdd((unsigned long long *)&diag[3 + 2 * dir], 1ull);
+            if (err == err)
+                atomicMax((unsigned long long *)&diag[4 + 2 * dir], (unsigned long long)__double_as_longlong(err));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// spike-triggered sums  G1(a,k) = sum_t' rho_a(t') y[t'+k-1],  G2 likewise with y^2
+// (baumwelch.jl:270-282, :297-305); y beyond the end of the data is 0.
+// Generic vector kernel (any N, L): block = 4096 onsets, sub-tiles of 256 staged in LDS, one
+// thread per (ring, phase) pair.
+// ------------------------------------------------------------------------------------------
+constexpr int kGsTile = 4096, kGsSub = 256;
+
+__global__ __launch_bounds__(256) void kw_gsum_generic(WaveGeom g, const double *__restrict__ y,
+                                                       const double *__restrict__ rho, int nparts,
+                                                       double *__restrict__ partG)
+{
+    extern __shared__ double lds[];
+    const int N = g.N, L = g.L, NL = N * L, ch = blockIdx.y;
+    double *lr = lds;                 // [N][kGsSub]
+    double *ly = lds + N * kGsSub;    // [kGsSub + L]
+    const int64_t T = g.T, t0 = (int64_t)blockIdx.x * kGsTile;
+    const double *yc = y + (int64_t)ch * T, *rc = rho + (int64_t)ch * N * T;
+    const int p = threadIdx.x + 256 * blockIdx.z;   // this thread's (ring, phase) pair
+    const int a = p < NL ? p / L : 0, k = p < NL ? p % L : 0;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s0 = 0; s0 < kGsTile; s0 += kGsSub) {
+        const int64_t tb = t0 + s0;
+        if (tb >= T) break;
+        __syncthreads();
+        for (int i = threadIdx.x; i < N * kGsSub; i += 256) {
+            const int aa = i / kGsSub, u = i % kGsSub;
+            const int64_t t = tb + u;
+            lr[i] = t < T ? rc[(int64_t)aa * T + t] : 0.0;
+        }
+        for (int i = threadIdx.x; i < kGsSub + L; i += 256) {
+            const int64_t t = tb + i;
+            ly[i] = t < T ? yc[t] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int u = 0; u < kGsSub; u++) {
+            const double r = lr[a * kGsSub + u], yv = ly[u + k];
+            s1 = __builtin_fma(r, yv, s1);
+            s2 = __builtin_fma(r * yv, yv, s2);
+        }
+    }
+    double *out = partG + ((int64_t)ch * nparts + blockIdx.x) * 2 * NL;
+    if (p < NL) { out[p] = s1; out[NL + p] = s2; }
+}
+
+// Matrix-core statistics for few rings (N <= 8): see the derivation at k_gsum_mx (ring_estep.hip).
+// The 16 columns of the B operand hold NS = 16/NP delayed copies of the NP rings, so one
+// v_mfma_f64_16x16x4_f64 accumulates LPT = 16 NS consecutive lags of every ring with no padded
+// column.  Natural layout: a "column" is a block of kGxBv consecutive samples; a workgroup sweeps 64
+// columns as 8 groups of 8, wave w takes columns 2w, 2w+1 of a group; tiles of TR rows staged
+// through LDS with all global loads contiguous in time.
+typedef double wg_d4 __attribute__((ext_vector_type(4)));
+constexpr int kGxTR = 64, kGxBv = 256;
+
+template <int N, int NT>
+__global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__restrict__ y,
+                                                  const double *__restrict__ rho, int nparts,
+                                                  double *__restrict__ partG)
+{
+    constexpr int NP = N <= 1 ? 1 : (N <= 2 ? 2 : (N <= 4 ? 4 : 8));
+    constexpr int NS = 16 / NP, LPT = 16 * NS, HS = 16 * (NS - 1);
+    constexpr int TR = kGxTR, CW = 8, RR = TR + HS, Bv = kGxBv;
+    extern __shared__ double lds[];
+    const int L = g.L, ch = blockIdx.y;
+    const int64_t T = g.T;
+    constexpr int YR = TR + 19 + LPT * (NT - 1);   // staged y rows per column (odd)
+    constexpr int RS = RR * NP + 2;                // rho column stride
+    double *lr = lds;                              // [CW][RS]
+    double *ly = lds + CW * RS;                    // [CW][YR]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lk = lane >> 4, lj = lane & 15, la = lj % NP, lsft = lj / NP;
+    const double *yc = y + (int64_t)ch * T, *rc = rho + (int64_t)ch * N * T;
+    wg_d4 c1[NT], c2[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++) { c1[q] = wg_d4{0.0, 0.0, 0.0, 0.0}; c2[q] = wg_d4{0.0, 0.0, 0.0, 0.0}; }
+    for (int sub = 0; sub < 64 / CW; sub++) {
+        const int64_t col0 = (int64_t)blockIdx.x * 64 + sub * CW;
+        if (col0 * Bv >= T) break;
+        for (int s0 = 0; s0 < Bv + HS; s0 += TR) {
+            constexpr int NRH = (NP * RR * CW + 255) / 256, NYM = (CW * (YR - 1) + 255) / 256;
+            double tr_[NRH], ty_[NYM];
+#pragma unroll
+            for (int k = 0; k < NRH; k++) {   // rho rows s0-HS .. s0+TR-1 of every column, time fastest
+                const int i = tid + k * 256;
+                const int u = i % RR, rest = i / RR, cc = rest % CW, a = rest / CW;
+                const int row = s0 - HS + u;
+                const int64_t t = (col0 + cc) * Bv + row;
+                const bool ok = i < NP * RR * CW && a < N && row >= 0 && row < Bv && t < T;
+                const double v = rc[ok ? (int64_t)a * T + t : 0];
+                tr_[k] = ok ? v : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < NYM; k++) {   // y rows s0 .. s0+YR-2
+                const int i = tid + k * 256;
+                const int rr = i % (YR - 1), cc = i / (YR - 1);
+                const int64_t t = (col0 + cc) * Bv + s0 + rr;
+                const bool ok = i < CW * (YR - 1) && t < T;
+                const double v = yc[ok ? t : 0];
+                ty_[k] = ok ? v : 0.0;
+            }
+            __syncthreads();  // the previous tile has been consumed
+#pragma unroll
+            for (int k = 0; k < NRH; k++) {
+                const int i = tid + k * 256;
+                const int u = i % RR, rest = i / RR, cc = rest % CW, a = rest / CW;
+                if (i < NP * RR * CW) lr[cc * RS + u * NP + a] = tr_[k];
+            }
+#pragma unroll
+            for (int k = 0; k < NYM; k++) {
+                const int i = tid + k * 256;
+                if (i < CW * (YR - 1)) ly[(i / (YR - 1)) * YR + i % (YR - 1)] = ty_[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < CW / 4; h++) {
+                const int cc = wv * (CW / 4) + h;
+                const double *lrc = lr + cc * RS + (lk - 16 * lsft + HS) * NP + la;
+                const double *lyc = ly + cc * YR + lk + lj;
+#pragma unroll 4
+                for (int ts = 0; ts < TR / 4; ts++) {
+                    const double b = lrc[ts * 4 * NP];
+#pragma unroll
+                    for (int q = 0; q < NT; q++) {
+                        const double a = lyc[ts * 4 + q * LPT];
+                        c1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1[q], 0, 0, 0);
+                        c2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a * a, b, c2[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // sum the four waves' tiles: LDS [wave][NT][2][4 regs][64 lanes]
+    __syncthreads();
+    double *red = lds;
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            red[(((wv * NT + q) * 2 + 0) * 4 + r) * 64 + lane] = c1[q][r];
+            red[(((wv * NT + q) * 2 + 1) * 4 + r) * 64 + lane] = c2[q][r];
+        }
+    }
+    __syncthreads();
+    const int NL = N * L;
+    double *out = partG + ((int64_t)ch * nparts + blockIdx.x) * 2 * NL;
+    for (int e = tid; e < NT * 2 * 4 * 64; e += 256) {
+        const int ln = e & 63, r = (e >> 6) & 3, which = (e >> 8) & 1, q = e >> 9;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) v += red[(((w * NT + q) * 2 + which) * 4 + r) * 64 + ln];
+        const int j = ln & 15, a = j % NP, sft = j / NP;
+        const int lag = q * LPT + 16 * sft + (ln >> 4) + 4 * r;
+        if (a < N && lag < L) out[which * NL + a * L + lag] = v;
+    }
+}
+
+// virtual onsets t' = -j (rings already running at the first sample), the end-of-data correction of
+// G0 and pp = gamma[:,1] (baumwelch.jl:263).  One thread per ring state, one block row per channel.
+//   extra[0..NL)    = G0 of the virtual onsets + sum of rho over the onsets of the last L-1 samples
+//                     that still reach phase k (kw_bwd leaves those out of its total)
+//   extra[NL..2NL)  = G1 of the virtual onsets,  extra[2NL..3NL) = G2 of the virtual onsets
+__global__ __launch_bounds__(64) void kw_edges(WaveGeom g, const double *__restrict__ y,
+                                               const double *__restrict__ Rf, const double *__restrict__ virt,
+                                               const double *__restrict__ FA0, const double *__restrict__ rho,
+                                               const double *__restrict__ Zc, const double *__restrict__ yhead,
+                                               double *__restrict__ extra, double *__restrict__ pp)
+{
+    const int L = g.L, N = g.N, NL = N * L, ch = blockIdx.y, S = 1 + NL;
+    const int64_t T = g.T;
+    const double *yc = y + (int64_t)ch * T, *rc = rho + (int64_t)ch * N * T;
+    const double *yh = yhead + (int64_t)ch * (NL + 2);
+    const double z = Zc[(int64_t)ch * g.nch];
+    for (int pair = blockIdx.x * blockDim.x + threadIdx.x; pair < NL; pair += gridDim.x * blockDim.x) {
+        const int a = pair / L, k = pair % L + 1;
+        const double *V = virt + ((int64_t)ch * N + a) * (L + 1);
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+        for (int j = 1; j <= L - 1 && g.first; j++) {  // virtual onsets exist at the recording start only
+            const int idx = -j + k - 1;
+            if (idx < 0) continue;
+            const double rv = fexp((V[j] + yh[a * L + (L - 1 - j)]) - z);
+            const double yv = yc[idx];
+            g0 += rv; g1 += rv * yv; g2 += rv * (yv * yv);
+        }
+        double tail = 0.0;
+        if (g.last)
+            for (int64_t t = T - L + 1; t <= T - k; t++)
+                if (t >= 0) tail += rc[(int64_t)a * T + t];
+        double *ex = extra + (int64_t)ch * 3 * NL;
+        ex[pair] = g0 + tail;
+        ex[NL + pair] = g1;
+        ex[2 * NL + pair] = g2;
+        const double lpv = k == 1 ? Rf[((int64_t)ch * N + a) * T] : V[k - 1];
+        pp[(int64_t)ch * S + 1 + pair] = (lpv + yh[a * L + (L - k)]) - z;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) pp[(int64_t)ch * S] = (FA0[(int64_t)ch * T] + yh[NL]) - z;
+}
+
+// deterministic final assembly: stats[ch] = [G0 | G1 | G2 | Xi' | s_all | s_m | s_y2 | 0]
+__global__ __launch_bounds__(64) void kw_stats_final(WaveGeom g, int rowsG, const double *__restrict__ partG,
+                                                     const double *__restrict__ partS,
+                                                     const double *__restrict__ extra, double *__restrict__ stats)
+{
+    const int N = g.N, L = g.L, i = blockIdx.x, ch = blockIdx.y, lane = threadIdx.x;
+    const int NL = N * L, ws = 2 * N + 3, total = 3 * NL + N + 4;
+    const double *pS = partS + (int64_t)ch * g.nch * ws;
+    const double *pG = partG + (int64_t)ch * rowsG * 2 * NL;
+    double acc = 0.0;
+    if (i < NL) {
+        const int a = i / L;
+        for (int r = lane; r < g.nch; r += 64) acc += pS[(size_t)r * ws + N + a];
+    } else if (i < 3 * NL) {
+        const int e = i - NL;
+        for (int r = lane; r < rowsG; r += 64) acc += pG[(size_t)r * 2 * NL + e];
+    } else if (i < 3 * NL + N) {
+        for (int r = lane; r < g.nch; r += 64) acc += pS[(size_t)r * ws + (i - 3 * NL)];
+    } else if (i < 3 * NL + N + 3) {
+        for (int r = lane; r < g.nch; r += 64) acc += pS[(size_t)r * ws + 2 * N + (i - 3 * NL - N)];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) stats[(int64_t)ch * total + i] = acc + (i < 3 * NL ? extra[(int64_t)ch * 3 * NL + i] : 0.0);
+}
+
+// M-step finish (baumwelch.jl:262-307) from the (possibly all-reduced) statistics.
+// out[ch] = [mu (K x N col-major) | sigma | lp_new (N) | pp (S)]
+__global__ __launch_bounds__(256) void kw_mstep(WaveGeom g, const WaveConst *__restrict__ cst,
+                                                const double *__restrict__ stats_all,
+                                                const double *__restrict__ pp_all, double *__restrict__ out_all)
+{
+    __shared__ double red[8];
+    const int N = g.N, L = g.L, NL = N * L, K = L + 1, ch = blockIdx.x, S = 1 + NL;
+    const double *stats = stats_all + (int64_t)ch * (3 * NL + N + 4);
+    const double *pp = pp_all + (int64_t)ch * S;
+    double *out = out_all + (int64_t)ch * (K * N + 1 + N + S);
+    const double *G0 = stats, *G1 = stats + NL, *G2 = stats + 2 * NL, *Xi = stats + 3 * NL;
+    const double s_all = stats[3 * NL + N], s_m = stats[3 * NL + N + 1], s_y2 = stats[3 * NL + N + 2];
+    double x2 = 0.0, qq = 0.0;
+    for (int p = threadIdx.x; p < NL; p += blockDim.x) {
+        const int a = p / L, k = p % L + 1;
+        const double mu = G1[p] / G0[p];                 // :285  mu[j,l] /= gg[j,l]
+        out[k + K * a] = mu;
+        x2 += (G2[p] - (2.0 * mu) * G1[p]) + (mu * mu) * G0[p];
+        qq += G0[p];
+    }
+    for (int a = threadIdx.x; a < N; a += blockDim.x) {
+        out[K * a] = 0.0;                                // row 1 stays 0 (:268 fill!, never updated)
+        // :264 xb[2:end]; Xi' excludes the coefficient exp(c0_a - sc_a), added back in the log domain
+        out[K * N + 1 + a] = (cst[ch].xishift[a] + flog(Xi[a])) - flog(s_m);
+    }
+    for (int j = threadIdx.x; j < S; j += blockDim.x) out[K * N + 1 + N + j] = pp[j];
+    x2 = wave_sum(x2); qq = wave_sum(qq);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = x2; red[4 + (threadIdx.x >> 6)] = qq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double X2 = ((red[0] + red[1]) + (red[2] + red[3])) + s_y2;
+        const double QQ = ((red[4] + red[5]) + (red[6] + red[7])) + s_all;
+        out[K * N] = sqrt(X2 / QQ);                      // :306-307
+    }
+}
+
+template <typename Kern>
+static int wave_lds_attr2(Kern kern, size_t lds)
+{
+    if (lds > 64 * 1024)
+        HS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return HMMSORT_OK;
+}
+
+static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hipStream_t st)
+{
+    const WaveGeom &g = r->g;
+    const int N = g.N, L = g.L, NL = N * L;
+    const int nchT = g.C * g.nch;
+    int rowsG = 0;
+    int rc = dispatch_N(N, [&](auto n) {
+        constexpr int NN = decltype(n)::value;
+        const size_t ldsf = (size_t)2 * NN * g.RB * sizeof(double), ldsb = (size_t)(NN + 1) * g.RB * sizeof(double);
+        int rc2;
+        if ((rc2 = wave_lds_attr2(kw_fwd<NN>, ldsf)) || (rc2 = wave_lds_attr2(kw_bwd<NN>, ldsb))) return rc2;
+        { WPROF(r, "kw_fwd", st);
+          hipLaunchKernelGGL((kw_fwd<NN>), dim3(nchT), dim3(64), ldsf, st, g, r->d_cst, d_y, r->Rf, r->virt, r->FA0,
+                             r->FV, r->FREF, r->fpre); }
+        { WPROF(r, "kw_bwd", st);
+          hipLaunchKernelGGL((kw_bwd<NN>), dim3(nchT), dim3(64), ldsb, st, g, r->d_cst, d_y, r->Rf, r->FA0, r->FV,
+                             r->FREF, r->fpre, r->rho, r->partS, r->Zc, r->bpre, r->bown, r->yhead); }
+        HS_HIP(hipGetLastError());
+        // certificate + edge terms beside the statistics kernel
+        HS_HIP(hipEventRecord(r->ev_a, st));
+        HS_HIP(hipStreamWaitEvent(r->side, r->ev_a, 0));
+        { WPROF(r, "kw_edges", r->side);
+          hipLaunchKernelGGL(kw_edges, dim3((NL + 63) / 64, g.C), dim3(64), 0, r->side, g, d_y, r->Rf, r->virt, r->FA0,
+                             r->rho, r->Zc, r->yhead, r->extra, r->pp); }
+        if (g.nch > 1) {
+            WPROF(r, "kw_fb_check", r->side);
+            hipLaunchKernelGGL(kw_fb_check, dim3(nchT), dim3(64), 0, r->side, g, 1e-9, r->FA0, r->FV, r->FREF, r->fpre,
+                               r->bpre, r->bown, r->rho, r->diag, r->dbg);
+        }
+        HS_HIP(hipEventRecord(r->ev_b, r->side));
+        constexpr int NPx = NN <= 1 ? 1 : (NN <= 2 ? 2 : (NN <= 4 ? 4 : 8));
+        constexpr int LPTx = 16 * (16 / NPx), HSx = LPTx - 16;
+        const int ntx = (L + LPTx - 1) / LPTx;
+        const bool generic = getenv("HMMSORT_GSUM_GENERIC") != nullptr;
+        if (!generic && NN <= 8 && ntx <= 4) {
+            rowsG = (int)((g.T + 64 * (int64_t)kGxBv - 1) / (64 * (int64_t)kGxBv));
+            const size_t l1 = ((size_t)8 * ((kGxTR + HSx) * NPx + 2) + (size_t)8 * (kGxTR + 19 + LPTx * (ntx - 1))) * 8;
+            const size_t l2 = (size_t)4 * ntx * 2 * 4 * 64 * 8;
+            const size_t lds = l1 > l2 ? l1 : l2;
+            constexpr int NM = NN <= 8 ? NN : 8;
+            auto go = [&](auto kern) -> int {
+                int rc3 = wave_lds_attr2(kern, lds);
+                if (rc3) return rc3;
+                WPROF(r, "kw_gsum", st);
+                hipLaunchKernelGGL(kern, dim3(rowsG, g.C), dim3(256), lds, st, g, d_y, r->rho, rowsG, r->partG);
+                return HMMSORT_OK;
+            };
+            rc2 = ntx == 1 ? go(kw_gsum_mx<NM, 1>) : ntx == 2 ? go(kw_gsum_mx<NM, 2>)
+                : ntx == 3 ? go(kw_gsum_mx<NM, 3>) : go(kw_gsum_mx<NM, 4>);
+            if (rc2) return rc2;
+        } else {
+            rowsG = r->gparts;
+            const size_t lds = ((size_t)NN * kGsSub + kGsSub + L) * sizeof(double);
+            WPROF(r, "kw_gsum", st);
+            hipLaunchKernelGGL(kw_gsum_generic, dim3(rowsG, g.C, (NL + 255) / 256), dim3(256), lds, st, g, d_y, r->rho, rowsG, r->partG);
+        }
+        HS_HIP(hipGetLastError());
+        return HMMSORT_OK;
+    });
+    if (rc) return rc;
+    HS_HIP(hipStreamWaitEvent(st, r->ev_b, 0));
+    const int total = 3 * NL + N + 4;
+    { WPROF(r, "kw_stats_final", st);
+      hipLaunchKernelGGL(kw_stats_final, dim3(total, g.C), dim3(64), 0, st, g, rowsG, r->partG, r->partS, r->extra,
+                         d_stats); }
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+int wave_estep(WaveDev *r, const double *d_y, double *d_stats, hipStream_t st)
+{
+    int rc;
+    HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
+    if ((rc = wave_prepare(r, d_y, st))) return rc;
+    return wave_estep_sweeps(r, d_y, d_stats, st);
+}
+
+int wave_mstep(WaveDev *r, const double *d_stats, double *d_out, hipStream_t st)
+{
+    { WPROF(r, "kw_mstep", st);
+      hipLaunchKernelGGL(kw_mstep, dim3(r->g.C), dim3(256), 0, st, r->g, r->d_cst, d_stats, r->pp, d_out); }
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+// one decode + one E-step of the same signal and model: the Viterbi sweep with its post-processing
+// runs on the plan's second internal stream beside the forward/backward sweeps
+int wave_decode_estep(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll, double *d_stats, hipStream_t st)
+{
+    int rc;
+    HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
+    if ((rc = wave_prepare(r, d_y, st))) return rc;
+    if ((rc = wave_viterbi_sweep(r, d_y, st))) return rc;
+    if ((rc = wave_viterbi_post(r, d_y, d_x, d_ll, st))) return rc;
+    return wave_estep_sweeps(r, d_y, d_stats, st);
+}
+
+}  // namespace hmmsort

@@ -1,0 +1,615 @@
+// Wave engine, part 2: time-parallel Viterbi (reference src/viterbi.jl:44-98), one wavefront per
+// chain.  Specification: tests/wave_model.py (vit_chain / vit_decode).
+//
+// Per sample t the recursion keeps, per chain:
+//   D0(t)     = delta_t(silent)
+//   P_a(t')   = delta of ring a's LAST state at t'+L-1 for the onset at t' = U_a(t') + Rfull_a(t'),
+//               U_a(t') = best predecessor score of state (a,1) at t'
+// and decides the back-pointer psi in {0 = silent, b = ring b's last state} of the N+1 junction
+// states; candidates are scanned in source-state order (silent first, rings ascending) with a strict
+// '>' -- the reference's tie rule (viterbi.jl:74-84).  Frame: delta'_t = delta_t - A*(t+1).
+//
+// A wavefront advances W = min(L, 64) samples per super-step: lane j owns sample t0 + j, the ring
+// exits X_a(t) = P_a(t-L) it needs were produced in earlier super-steps (LDS delay line), so
+// D0(t) = max(D0(t-1) + c00 + q0(t), max_a(X_a(t) + cend_a) + q0(t)) is a first-order max-plus
+// recurrence across the lanes: one 6-level scan.  Every other quantity of the W samples is lane-local.
+//
+// Exactness.  (1) Chain starts: a chain starts Hw samples early from "silent, rings empty"; after the
+// sweep its state at tc-1 is compared with the state the previous chain really ended on, ALL 1 + N*L
+// entries up to one common constant (tolerance 1e-9); a chain that misses the certificate is swept
+// again from the previous chain's exact end state (kw_vit with redo = 1), so the stored
+// back-pointers are those of one sequential sweep.  (2) Rounding: inside a chain the arithmetic
+// differs from the reference's by rounding at the 1e-13 level (pre-summed ring scores, scan order,
+// per-chain offsets instead of the reference's O(t) cumulative sum, whose own rounding unit is
+// larger).  Every decision records whether its winner beat the runner-up by less than
+// thr = 16 (L+2) ulp(|T1|max) + 4e-9 -- a bound on what the reference's own rounding plus ours can
+// move a difference between two paths -- and the backtrace counts the flagged decisions ON THE
+// DECODED PATH in diag[7]: 0 means the path is the reference's bit for bit; otherwise the host entry
+// points decode with the strict engine.
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+
+#include "wave_common.h"
+
+namespace hmmsort {
+
+constexpr double kVitTol = 1e-9;
+
+template <int N>
+struct WIn {
+    double y;
+    double R[N];
+};
+
+__device__ __forceinline__ double wave_thr(const WaveGeom &g, const WaveConst &K, const double *__restrict__ ysum, int ch)
+{
+    // largest magnitude the reference's trellis reaches: |sum_t (A - d^2/den + lp)| <= ...
+    const double T = (double)g.T;
+    const double s1 = ysum[2 * ch], s2 = ysum[2 * ch + 1];
+    const double sq = fmax((s2 - 2.0 * K.mean0 * s1) + T * K.mean0 * K.mean0, 0.0);
+    const double mmax = fabs(K.A) * T + sq / K.den + fabs(K.c00) * T + 1.0;
+    return ldexp(16.0 * (double)(g.L + 2), ilogb(mmax) - 52) + 4.0 * kVitTol;
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void kw_vit(WaveGeom g, const WaveConst *__restrict__ cst,
+                                             const double *__restrict__ y, const double *__restrict__ Rf,
+                                             const double *__restrict__ virt,
+                                             const double *__restrict__ ysum, uint32_t *__restrict__ psi,
+                                             double *__restrict__ vpre, double *__restrict__ vend,
+                                             const int32_t *__restrict__ vfail, int redo)
+{
+    constexpr int EB = wpsi_bits_c(N), EPW = wpsi_epw_c(N), PW = wpsi_words_c(N);
+    extern __shared__ double DL[];  // [N][RB] delay line: P_a(t') at slot (t' - tinit + L) mod RB
+    const int lane = threadIdx.x;
+    const int cg = blockIdx.x, ch = cg / g.nch, c = cg % g.nch;
+    if (redo && (c == 0 || vfail[cg] == 0 || vfail[cg - 1] != 0)) return;  // wave-uniform
+    const WaveConst &K = cst[ch];
+    const int L = g.L, W = g.W, RB = g.RB, B = g.B;
+    const int64_t T = g.T;
+    const int64_t tc = (int64_t)c * B;
+    const int nc = (int)((T - tc) < B ? (T - tc) : B);
+    const int64_t tend = tc + nc;
+    const double *yc = y + (int64_t)ch * T;
+    const double *Rc = Rf + (int64_t)ch * N * T;
+    const int64_t SR = 1 + N * L;
+    const int64_t planePsi = (int64_t)g.C * T;
+    const double thr = wave_thr(g, K, ysum, ch);
+
+    for (int i = lane; i < N * RB; i += 64) DL[i] = -INFINITY;
+    __syncthreads();
+    int64_t tinit;
+    double D0;
+    if (redo) {            // exact hand-off: the previous chain's end state
+        tinit = tc - 1;
+        D0 = vend[(cg - 1) * SR];
+        for (int i = lane; i < N * L; i += 64) {
+            const int a = i / L, j = i % L + 1;
+            DL[a * RB + (L + 1 - j)] = vend[(cg - 1) * SR + 1 + i];
+        }
+    } else if (c == 0) {   // the reference's first column (viterbi.jl:55-63): emission only, T1[1,1] = 0
+        tinit = 0;
+        D0 = -K.A;
+        for (int i = lane; i < N * L; i += 64) {
+            const int a = i / L, j = i % L + 1;  // virtual onset -j -> slot L - j
+            DL[a * RB + (L - j)] = virt[((int64_t)ch * N + a) * (L + 1) + j];
+        }
+        if (lane < N) DL[lane * RB + L] = Rc[(int64_t)lane * T];
+    } else {               // warm-up start: silent, rings empty
+        tinit = tc - g.Hw;
+        D0 = 0.0;
+    }
+    __syncthreads();
+
+    const int n_total = (int)(tend - 1 - tinit);  // steps t = tinit+1 .. tend-1
+    auto load = [&](WIn<N> &d, int off) {
+        const int nact = n_total - off < W ? n_total - off : W;
+        int64_t t = tinit + 1 + off + (lane < nact ? lane : 0);
+        t = t < T ? t : T - 1;
+        d.y = yc[t];
+#pragma unroll
+        for (int a = 0; a < N; a++) d.R[a] = Rc[(int64_t)a * T + t];
+    };
+    int rs = (1 + lane) % RB, ws = (L + 1 + lane) % RB;
+    auto run = [&](const WIn<N> &d, int off) {
+        const int nact = n_total - off < W ? n_total - off : W;
+        const bool live = lane < nact;
+        const int64_t t = tinit + 1 + off + lane;
+        double X[N];
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            const double v = DL[a * RB + rs];
+            X[a] = live ? v : -INFINITY;
+        }
+        // ring exits into the silent state: best and runner-up among the rings
+        double e1 = -INFINITY, e2 = -INFINITY;
+        int earg = 0;
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            const double v = X[a] + K.cend[a];
+            if (v > e1) { e2 = e1; e1 = v; earg = a + 1; }
+            else e2 = fmax(e2, v);
+        }
+        const double dd = d.y - K.mean0;
+        const double q0 = -((dd * dd) / K.den);
+        double sa = live ? K.c00 + q0 : 0.0;
+        double sb = live ? e1 + q0 : -INFINITY;
+        scan_maxplus(sa, sb, lane);
+        const double D = fmax(D0 + sa, sb);
+        const double Dprev = lane_prev(D, D0, lane);
+        uint32_t pw[PW];
+#pragma unroll
+        for (int w = 0; w < PW; w++) pw[w] = 0u;
+        {
+            const double v0 = Dprev + K.c00;
+            const bool ring = e1 > v0;
+            const double best = ring ? e1 : v0;
+            const double sec = ring ? fmax(e2, v0) : e1;
+            const uint32_t fl = (best - sec) < thr ? 1u : 0u;
+            pw[0] = (ring ? (uint32_t)earg : 0u) | (fl << (EB - 1));
+        }
+        double Pn[N];
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+            double r1 = -INFINITY, r2 = -INFINITY;
+            int rarg = 0;
+#pragma unroll
+            for (int b = 0; b < N; b++) {
+                if (b == a) continue;
+                const double v = X[b] + K.cx[b * N + a];
+                if (v > r1) { r2 = r1; r1 = v; rarg = b + 1; }
+                else r2 = fmax(r2, v);
+            }
+            const double v0 = Dprev + K.c0[a];
+            const bool ring = r1 > v0;
+            const double u = ring ? r1 : v0;
+            const double sec = ring ? fmax(r2, v0) : r1;
+            const uint32_t fl = (u - sec) < thr ? 1u : 0u;
+            Pn[a] = u + d.R[a];
+            const uint32_t ent = (ring ? (uint32_t)rarg : 0u) | (fl << (EB - 1));
+            pw[(a + 1) / EPW] |= ent << (((a + 1) % EPW) * EB);
+        }
+        if (live) {
+#pragma unroll
+            for (int a = 0; a < N; a++) DL[a * RB + ws] = Pn[a];
+            if (t >= tc) {
+#pragma unroll
+                for (int w = 0; w < PW; w++) psi[w * planePsi + (int64_t)ch * T + t] = pw[w];
+            }
+        }
+        D0 = wave_bcast(D, 63);  // idle lanes carry the identity, so lane 63 holds the last live value
+        rs += W; rs = rs >= RB ? rs - RB : rs;
+        ws += W; ws = ws >= RB ? ws - RB : ws;
+    };
+    auto dump = [&](double *rec, int64_t tref) {   // state "just before tref": D0 and P_a(tref - j), j = 1..L
+        __syncthreads();
+        if (lane == 0) rec[0] = D0;
+        for (int i = lane; i < N * L; i += 64) {
+            const int a = i / L, j = i % L + 1;
+            const int slot = (int)((tref - j - tinit + L) % RB);
+            rec[1 + i] = DL[a * RB + slot];
+        }
+        __syncthreads();
+    };
+
+    WIn<N> bufA, bufB;
+    const int n_warm = (redo || c == 0) ? -1 : g.Hw - 1;
+    load(bufA, 0);
+    for (int off = 0; off < n_total; off += 2 * W) {
+        load(bufB, off + W);
+        run(bufA, off);
+        if (off + W == n_warm) dump(vpre + cg * SR, tc);
+        if (off + W < n_total) {
+            load(bufA, off + 2 * W);
+            run(bufB, off + W);
+            if (off + 2 * W == n_warm) dump(vpre + cg * SR, tc);
+        }
+    }
+    dump(vend + cg * SR, tend);
+    if (redo) {  // the hand-off was exact by construction
+        for (int i = lane; i < SR; i += 64) vpre[cg * SR + i] = vend[(cg - 1) * SR + i];
+    }
+}
+
+// Boundary certificate: one wavefront per chain boundary; all 1 + N*L entries of the warm-up state
+// must equal the previous chain's end state up to one constant.
+__global__ __launch_bounds__(64) void kw_vit_check(WaveGeom g, const double *__restrict__ vpre,
+                                                   const double *__restrict__ vend,
+                                                   int32_t *__restrict__ vfail, int64_t *__restrict__ diag,
+                                                   int final_round)
+{
+    const int lane = threadIdx.x;
+    const int cg = blockIdx.x, c = cg % g.nch;
+    if (c == 0) { if (lane == 0) vfail[cg] = 0; return; }
+    const int64_t SR = 1 + (int64_t)g.N * g.L;
+    double lo = INFINITY, hi = -INFINITY;
+    bool bad = false;
+    for (int64_t i = lane; i < SR; i += 64) {
+        const double p = vpre[cg * SR + i], e = vend[(cg - 1) * SR + i];
+        if (p == e) { lo = fmin(lo, 0.0); hi = fmax(hi, 0.0); continue; }  // covers -inf vs -inf
+        const double d = p - e;
+        if (!(fabs(d) < INFINITY)) { bad = true; continue; }                // NaN or one-sided infinity
+        lo = fmin(lo, d); hi = fmax(hi, d);
+    }
+    lo = -wave_max(-lo); hi = wave_max(hi);
+    const bool anybad = __any(bad);
+    const double spread = hi - lo;
+    const bool fail = anybad || !(spread <= kVitTol);
+    if (lane == 0) {
+        vfail[cg] = fail ? 1 : 0;
+        if (final_round) {
+            if (fail) atomicAdd((unsigned long long *)&diag[0], 1ull);
+            if (!anybad && spread == spread && spread < INFINITY)
+                atomicMax((unsigned long long *)&diag[2], (unsigned long long)__double_as_longlong(spread));
+        } else if (fail) {
+            atomicAdd((unsigned long long *)&diag[1], 1ull);  // chains swept again (all rounds)
+        }
+    }
+}
+
+// Final state = argmax over all S states at the last sample, first maximum in state order
+// (viterbi.jl:90).  delta(a,k) at T-1 is P_a(T-k).  One wave per channel.
+__global__ __launch_bounds__(64) void kw_vit_tail(WaveGeom g, const WaveConst *__restrict__ cst,
+                                                  const double *__restrict__ ysum,
+                                                  const double *__restrict__ vend,
+                                                  int32_t *__restrict__ final_state, int64_t *__restrict__ diag)
+{
+    const int lane = threadIdx.x, ch = blockIdx.x;
+    const int64_t SR = 1 + (int64_t)g.N * g.L;
+    const double *rec = vend + ((int64_t)ch * g.nch + g.nch - 1) * SR;
+    const int S = 1 + g.N * g.L;
+    double best = -INFINITY, sec = -INFINITY;
+    int bi = S;
+    for (int j = lane; j < S; j += 64) {  // state j = 1 + a*L + (k-1) <-> record entry 1 + a*L + (k-1)
+        const double v = rec[j];
+        if (v > best) { sec = best; best = v; bi = j; }
+        else sec = fmax(sec, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(best, o), os = __shfl_xor(sec, o);
+        const int oi = __shfl_xor(bi, o);
+        const bool take = ov > best || (ov == best && oi < bi);
+        const double lose = take ? best : ov;
+        sec = fmax(fmax(sec, os), lose);
+        if (take) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        final_state[ch] = (bi >= S) ? 0 : bi;
+        if ((best - sec) < wave_thr(g, cst[ch], ysum, ch)) atomicAdd((unsigned long long *)&diag[7], 1ull);
+    }
+}
+
+// Backtrace (viterbi.jl:93-94).  The path is cut into segments of Bb samples, one LANE per segment;
+// a lane starts its walk Hb samples after its segment's end from the silent state (from the true
+// final state where that is the end of the data) and has merged with the true path by the time it
+// enters its segment (checked: kw_stitch_*).  psi is in natural time order, so a tile of 64 segments
+// x 64 samples is read with coalesced rows into LDS and walked column-wise; x leaves the same way.
+// Flagged (near-tie) junction decisions met inside the owned segment are counted in diag[7].
+template <int N>
+__global__ __launch_bounds__(64) void kw_backtrace(WaveGeom g, const uint32_t *__restrict__ psi,
+                                                   const int32_t *__restrict__ final_state,
+                                                   int16_t *__restrict__ x, int32_t *__restrict__ bstate,
+                                                   int64_t *__restrict__ diag)
+{
+    constexpr int EB = wpsi_bits_c(N), EPW = wpsi_epw_c(N), PW = wpsi_words_c(N);
+    constexpr int TS = PW <= 2 ? 64 : 32;   // samples per tile (static LDS stays below 64 KB)
+    constexpr int RPI = 64 / TS;            // segment rows per load instruction
+    __shared__ uint32_t tile[PW][64][TS + 1];
+    __shared__ int16_t xt[64][TS + 2];
+    const int lane = threadIdx.x, ch = blockIdx.y;
+    const int L = g.L, Bb = g.Bb, Hb = g.Hb;
+    const int64_t T = g.T;
+    const int64_t sg0 = (int64_t)blockIdx.x * 64, sg = sg0 + lane;
+    const bool active = sg < g.nseg;
+    const int64_t s_lo = sg * Bb;
+    const int64_t s_hi = active ? ((s_lo + Bb) < T ? (s_lo + Bb) : T) : s_lo;
+    const int64_t te = (s_hi + Hb) < T ? (s_hi + Hb) : T;  // walk starts at te-1
+    const int64_t planePsi = (int64_t)g.C * T;
+    const uint32_t *pc = psi + (int64_t)ch * T;
+    int16_t *xc = x + (int64_t)ch * T;
+    int a = -1, k = 0;
+    if (active && te == T) {
+        const int fs = final_state[ch];
+        if (fs > 0) { a = (fs - 1) / L; k = (fs - 1) % L + 1; }
+    }
+    int nflag = 0;
+    const int lr = lane / TS, lc = lane % TS;
+    for (int q = (Bb + Hb) / TS - 1; q >= 0; q--) {
+        // stage psi rows: row r = segment sg0 + r, samples s_lo(r) + TS q + lc
+#pragma unroll 4
+        for (int rr = 0; rr < 64; rr += RPI) {
+            const int r = rr + lr;
+            const int64_t t = (sg0 + r) * Bb + (int64_t)TS * q + lc;
+            const bool ok = (sg0 + r) < g.nseg && t < T;
+#pragma unroll
+            for (int w = 0; w < PW; w++) {
+                const uint32_t v = pc[w * planePsi + (ok ? t : 0)];
+                tile[w][r][lc] = ok ? v : 0u;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = TS - 1; i >= 0; i--) {
+            const int64_t t = s_lo + (int64_t)TS * q + i;
+            const bool live = active && t < te;
+            const int id = (a < 0) ? 1 : 2 + a * L + (k - 1);
+            if (live && t <= s_hi) {
+                if (t < s_hi) xt[lane][i] = (int16_t)id;
+                else bstate[(int64_t)ch * g.nseg + sg] = id;
+            }
+            const int e = a + 1;
+            uint32_t wsel = tile[0][lane][i];
+#pragma unroll
+            for (int w = 1; w < PW; w++) wsel = (e / EPW == w) ? tile[w][lane][i] : wsel;
+            const uint32_t ent = (wsel >> ((e % EPW) * EB)) & ((1u << EB) - 1u);
+            const int p = (int)(ent & ((1u << (EB - 1)) - 1u));
+            const bool interior = (a >= 0) && (k > 1);
+            const bool step = live && t >= 1;
+            if (step && !interior && t < s_hi && t >= 2 && (ent >> (EB - 1))) nflag++;  // psi(1) only decides x[0]: kw_first_state
+            const int na = interior ? a : p - 1;
+            const int nk = interior ? k - 1 : (p == 0 ? 0 : L);
+            a = step ? na : a;
+            k = step ? nk : k;
+        }
+        __syncthreads();
+        if (TS * q < Bb) {  // owned rows: write x out, coalesced
+#pragma unroll 4
+            for (int rr = 0; rr < 64; rr += RPI) {
+                const int r = rr + lr;
+                const int64_t t = (sg0 + r) * Bb + (int64_t)TS * q + lc;
+                if ((sg0 + r) < g.nseg && t < T) xc[t] = xt[r][lc];
+            }
+        }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) nflag += __shfl_xor(nflag, o);
+    if (lane == 0 && nflag) atomicAdd((unsigned long long *)&diag[7], (unsigned long long)nflag);
+}
+
+__device__ __forceinline__ void wwalk_step(const WaveGeom &g, const uint32_t *__restrict__ pc, int64_t planePsi,
+                                           int64_t t, int &a, int &k, int64_t &nflag)
+{
+    if (a >= 0 && k > 1) { k--; return; }
+    const int e = a + 1;
+    const uint32_t w = pc[(int64_t)(e / g.epw) * planePsi + t];
+    const uint32_t ent = (w >> ((e % g.epw) * g.EB)) & ((1u << g.EB) - 1u);
+    const int p = (int)(ent & ((1u << (g.EB - 1)) - 1u));
+    if (t >= 2) nflag += ent >> (g.EB - 1);  // psi(1) only decides x[0], which kw_first_state re-decides exactly
+    if (p == 0) { a = -1; k = 0; }
+    else { a = p - 1; k = g.L; }
+}
+
+// Stitch check: the state segment s's walk had on the first sample of segment s+1 must equal what
+// segment s+1 emitted there; otherwise segment s is queued for a serial re-walk.
+__global__ void kw_stitch_check(WaveGeom g, const int16_t *__restrict__ x, const int32_t *__restrict__ bstate,
+                                int32_t *__restrict__ redo)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)g.C * g.nseg) return;
+    const int ch = (int)(i / g.nseg);
+    const int64_t sg = i % g.nseg;
+    if (sg >= g.nseg - 1) return;
+    if (bstate[i] != (int)x[(int64_t)ch * g.T + (sg + 1) * g.Bb]) {
+        const int slot = atomicAdd(&redo[0], 1);
+        redo[1 + slot] = (int32_t)i;
+    }
+}
+
+__global__ void kw_stitch_fix(WaveGeom g, const uint32_t *__restrict__ psi, int16_t *__restrict__ x,
+                              int32_t *__restrict__ bstate, const int32_t *__restrict__ redo,
+                              int64_t *__restrict__ diag)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = redo[0];
+    const int L = g.L, Bb = g.Bb;
+    const int64_t planePsi = (int64_t)g.C * g.T;
+    int64_t fixes = 0, nflag = 0;
+    for (int q = 0; q < n; q++) {
+        const int ch = (int)(redo[1 + q] / g.nseg);
+        int64_t sg = redo[1 + q] % g.nseg;
+        const uint32_t *pc = psi + (int64_t)ch * g.T;
+        int16_t *xc = x + (int64_t)ch * g.T;
+        while (sg >= 0) {
+            const int64_t tn = (sg + 1) * Bb;  // first sample of segment sg+1
+            const int want = xc[tn];
+            if (bstate[(int64_t)ch * g.nseg + sg] == want) break;
+            bstate[(int64_t)ch * g.nseg + sg] = want;
+            fixes++;
+            int a = -1, k = 0;
+            if (want > 1) { a = (want - 2) / L; k = (want - 2) % L + 1; }
+            wwalk_step(g, pc, planePsi, tn, a, k, nflag);
+            for (int64_t t = tn - 1; t >= sg * Bb; t--) {
+                xc[t] = (int16_t)((a < 0) ? 1 : 2 + a * L + (k - 1));
+                if (t == 0) break;
+                if (t > sg * Bb) wwalk_step(g, pc, planePsi, t, a, k, nflag);
+            }
+            sg--;  // did the first sample of segment sg change?  then segment sg-1 must be re-checked
+        }
+    }
+    diag[1] += fixes;
+    diag[7] += nflag;
+}
+
+// The first decoded state, exactly as the reference finds it: x[0] = psi_1(x[1]) and psi_1 only sees
+// the first trellis column, which is plain emission (viterbi.jl:55-63).  Template tails are ~1e-16, so
+// the "ring in its last phase at sample 0" candidates differ by a few ulps only; re-deciding this one
+// sample with the reference's own operations (strict '>', list order) makes it exact.
+__global__ void kw_first_state(WaveGeom g, const WaveConst *__restrict__ cst, const double *__restrict__ y,
+                               const double *__restrict__ mean, const double *__restrict__ ctab_all,
+                               int16_t *__restrict__ x)
+{
+    const int ch = blockIdx.x;
+    if (threadIdx.x != 0 || g.T < 2) return;
+    const int N = g.N, L = g.L, S = 1 + N * L;
+    const double *ctab = ctab_all + (int64_t)ch * (1 + 2 * N + N * N + N * L);
+    const double *c0 = ctab + 1, *cend = ctab + 1 + N, *cx = ctab + 1 + 2 * N, *cint = ctab + 1 + 2 * N + N * N;
+    const double *mc = mean + (int64_t)ch * S;
+    const double A = cst[ch].A, den = cst[ch].den;
+    int16_t *xc = x + (int64_t)ch * g.T;
+    const double y0 = y[(int64_t)ch * g.T];
+    auto T1 = [&](int a, int k) {  // funcl, utils.jl:4
+        const double dd = y0 - mc[1 + a * L + (k - 1)];
+        return A - (dd * dd) / den;
+    };
+    double best = -INFINITY;
+    int arg = 1;
+    auto cand = [&](int state, double t1, double lp) {
+        const double tt = t1 + lp;
+        if (tt > best) { best = tt; arg = state; }
+    };
+    const int x1 = xc[1];
+    if (x1 == 1) {
+        cand(1, 0.0, ctab[0]);
+        for (int a = 0; a < N; a++) cand(1 + a * L + L, T1(a, L), cend[a]);
+    } else {
+        const int b = (x1 - 2) / L, k = (x1 - 2) % L + 1;
+        if (k == 1) {
+            cand(1, 0.0, c0[b]);
+            for (int a = 0; a < N; a++)
+                if (a != b) cand(1 + a * L + L, T1(a, L), cx[a * N + b]);
+        } else {
+            cand(1 + b * L + (k - 1), T1(b, k - 1), cint[b * L + (k - 1)]);
+        }
+    }
+    xc[0] = (int16_t)arg;
+}
+
+// ll = sum_{t=1..T-1} T1[x_t, t]  (viterbi.jl:92-96) without the trellis:
+//   T1[x_t,t] = T1[x_0,0] + sum_{u=1..t} inc_u  =>  ll = (T-1) T1[x_0,0] + sum_u (T-u) inc_u.
+__device__ __forceinline__ double wpath_lp(int N, int L, const double *__restrict__ ctab, int xp, int xc)
+{
+    if (xp == 1) return xc == 1 ? ctab[0] : ctab[1 + (xc - 2) / L];
+    const int a = (xp - 2) / L, k = (xp - 2) % L + 1;
+    if (k < L) return ctab[1 + 2 * N + N * N + a * L + k];
+    if (xc == 1) return ctab[1 + N + a];
+    return ctab[1 + 2 * N + a * N + (xc - 2) / L];
+}
+
+__global__ __launch_bounds__(256) void kw_ll_partial(WaveGeom g, const WaveConst *__restrict__ cst,
+                                                     const double *__restrict__ y, const int16_t *__restrict__ x,
+                                                     const double *__restrict__ mean,
+                                                     const double *__restrict__ ctab_all, double *__restrict__ part)
+{
+    __shared__ double red[4];
+    const int ch = blockIdx.y, N = g.N, L = g.L, S = 1 + N * L;
+    const int64_t T = g.T;
+    const double *yc = y + (int64_t)ch * T, *mc = mean + (int64_t)ch * S;
+    const int16_t *xc = x + (int64_t)ch * T;
+    const double *ctab = ctab_all + (int64_t)ch * (1 + 2 * N + N * N + N * L);
+    const double A = cst[ch].A, den = cst[ch].den;
+    double acc = 0.0;
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; u < T;
+         u += (int64_t)gridDim.x * blockDim.x) {
+        const int xp = xc[u - 1], xn = xc[u];
+        const double d = yc[u] - mc[xn - 1];
+        const double inc = wpath_lp(N, L, ctab, xp, xn) + (A - (d * d) / den);
+        acc += (double)(T - u) * inc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int x0 = xc[0];
+        if (x0 != 1) {  // T1[1,1] = 0 for the silent state (viterbi.jl:63)
+            const double d = yc[0] - mc[x0 - 1];
+            acc += (double)(T - 1) * (A - (d * d) / den);
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(int64_t)ch * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void kw_sum_partials(const double *__restrict__ part, int n, double *__restrict__ out)
+{
+    __shared__ double red[4];
+    const int ch = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += part[(int64_t)ch * n + i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[ch] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <typename Kern>
+static int wave_lds_attr(Kern kern, size_t lds)
+{
+    if (lds > 64 * 1024)
+        HS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return HMMSORT_OK;
+}
+
+constexpr int kVitRounds = 2;  // certificate + re-sweep rounds run unconditionally on device
+
+int wave_viterbi_sweep(WaveDev *r, const double *d_y, hipStream_t st)
+{
+    const WaveGeom &g = r->g;
+    const int nchT = g.C * g.nch;
+    return dispatch_N(g.N, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        const size_t lds = (size_t)N * g.RB * sizeof(double);
+        int rc = wave_lds_attr(kw_vit<N>, lds);
+        if (rc) return rc;
+        { WPROF(r, "kw_vit", st);
+          hipLaunchKernelGGL((kw_vit<N>), dim3(nchT), dim3(64), lds, st, g, r->d_cst, d_y, r->Rf, r->virt, r->ysum,
+                             r->psi, r->vpre, r->vend, r->vfail, 0); }
+        HS_HIP(hipGetLastError());
+        return HMMSORT_OK;
+    });
+}
+
+// boundary certificates with exact re-sweeps, final state, backtrace + stitch, x[0], ll
+int wave_viterbi_post(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st)
+{
+    const WaveGeom &g = r->g;
+    const int nchT = g.C * g.nch;
+    int rc = dispatch_N(g.N, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        const size_t lds = (size_t)N * g.RB * sizeof(double);
+        for (int round = 0; round < kVitRounds && g.nch > 1; round++) {
+            { WPROF(r, "kw_vit_check", st);
+              hipLaunchKernelGGL(kw_vit_check, dim3(nchT), dim3(64), 0, st, g, r->vpre, r->vend, r->vfail, r->diag, 0); }
+            { WPROF(r, "kw_vit_redo", st);
+              hipLaunchKernelGGL((kw_vit<N>), dim3(nchT), dim3(64), lds, st, g, r->d_cst, d_y, r->Rf, r->virt,
+                                 r->ysum, r->psi, r->vpre, r->vend, r->vfail, 1); }
+        }
+        { WPROF(r, "kw_vit_check", st);
+          hipLaunchKernelGGL(kw_vit_check, dim3(nchT), dim3(64), 0, st, g, r->vpre, r->vend, r->vfail, r->diag, 1); }
+        { WPROF(r, "kw_vit_tail", st);
+          hipLaunchKernelGGL(kw_vit_tail, dim3(g.C), dim3(64), 0, st, g, r->d_cst, r->ysum, r->vend, r->final_state,
+                             r->diag); }
+        HS_HIP(hipMemsetAsync(r->redo, 0, sizeof(int32_t), st));
+        { WPROF(r, "kw_backtrace", st);
+          hipLaunchKernelGGL((kw_backtrace<N>), dim3((unsigned)((g.nseg + 63) / 64), g.C), dim3(64), 0, st, g, r->psi,
+                             r->final_state, d_x, r->bstate, r->diag); }
+        HS_HIP(hipGetLastError());
+        return HMMSORT_OK;
+    });
+    if (rc) return rc;
+    const int64_t nsegT = (int64_t)g.C * g.nseg;
+    { WPROF(r, "kw_stitch_check", st);
+      hipLaunchKernelGGL(kw_stitch_check, dim3((unsigned)((nsegT + 255) / 256)), dim3(256), 0, st, g, d_x, r->bstate,
+                         r->redo); }
+    { WPROF(r, "kw_stitch_fix", st);
+      hipLaunchKernelGGL(kw_stitch_fix, dim3(1), dim3(64), 0, st, g, r->psi, d_x, r->bstate, r->redo, r->diag); }
+    { WPROF(r, "kw_first_state", st);
+      hipLaunchKernelGGL(kw_first_state, dim3(g.C), dim3(64), 0, st, g, r->d_cst, d_y, r->d_mean, r->d_ctab, d_x); }
+    { WPROF(r, "kw_ll_partial", st);
+      hipLaunchKernelGGL(kw_ll_partial, dim3(r->nparts, g.C), dim3(256), 0, st, g, r->d_cst, d_y, d_x, r->d_mean,
+                         r->d_ctab, r->part); }
+    { WPROF(r, "kw_sum_partials", st);
+      hipLaunchKernelGGL(kw_sum_partials, dim3(g.C), dim3(256), 0, st, r->part, r->nparts, d_ll); }
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+int wave_viterbi(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st)
+{
+    int rc;
+    HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
+    if ((rc = wave_prepare(r, d_y, st))) return rc;
+    if ((rc = wave_viterbi_sweep(r, d_y, st))) return rc;
+    return wave_viterbi_post(r, d_y, d_x, d_ll, st);
+}
+
+}  // namespace hmmsort

@@ -58,6 +58,9 @@ typedef struct hmm_trans {
 #define HMMSORT_ENGINE_RING 2   /* time-parallel ring engine or fail with HMMSORT_EUNSUP */
 #define HMMSORT_ENGINE_BLOCKED 3 /* any transition list (overlap models): the strict recursion run
                                     time-parallel over blocks with a certified warm-up */
+#define HMMSORT_ENGINE_WAVE 4   /* no-overlap ring models, one wavefront per chain of a few thousand
+                                   samples (lane scans; delay lines in LDS); AUTO's choice for ring
+                                   models.  HMMSORT_ENGINE_RING = the older lane-per-chain engine */
 
 const char *hmmsort_last_error(void);
 int hmmsort_version(void);

@@ -20,8 +20,9 @@ def big(H):
     return dict(K=K, N=N, temps=temps, pp=pp, y=y, onsets=onsets, sm=sm)
 
 
-def test_ring_decode_equals_strict_decode_at_10M(H, big):
-    H.set_option("engine", H.ENGINE_RING)
+@pytest.mark.parametrize("engine", ["wave", "ring"])
+def test_ring_decode_equals_strict_decode_at_10M(H, big, engine):
+    H.set_option("engine", H.ENGINE_WAVE if engine == "wave" else H.ENGINE_RING)
     x, ll = H.viterbi(big["y"], big["sm"], big["temps"], 0.3)
     assert H.get_option("last_escalations") == 0
     H.set_option("engine", H.ENGINE_STRICT)

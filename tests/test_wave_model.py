@@ -114,3 +114,24 @@ def test_estep_model_random_start_and_vanishing_template(O, H, lp_dead):
     assert np.allclose(mu[:, live], omu[:, live], rtol=1e-8, atol=1e-11)
     if len(live) == N:
         assert abs(sigma - osig) <= 1e-9 * osig
+
+
+def test_estep_model_chain_starting_inside_a_large_spike(O, H):
+    """a warm-up that starts in the middle of a spike: the scale of the silent path falls by
+    thousands of nats while the delay line still holds its empty entries (mantissa 0, scale 0):
+    0 * exp(+big) must not turn into NaN (found on the GPU: 16 x 200 model, T = 14 000)"""
+    N, K, T, B, Hh = 2, 80, 3000, 1024, 512
+    y, sm, temps = _case(H, N, K, T, 41)
+    for c in (1, 2):
+        t0 = c * B - (1 + ((Hh + 63) // 64) * 64) - 20
+        y[t0:t0 + K] += 2.5 * temps[:, 1]
+    osm = to_oracle_sm(O, sm)
+    mu0 = np.asfortranarray(temps * 0.9)
+    mu0[0, :] = 0
+    m = WM.Ring(sm, mu0, 0.25)
+    mu, sigma, lp_new, pp, g0, rho = WM.estep(y, m, B, Hh)
+    _, omu, osig, olp, opp = O.train_step(y, osm, mu0.copy(order="F"), 0.25)
+    assert np.all(np.isfinite(mu[1:]))
+    # the warm-up really starts in the wrong state here: its error has decayed to ~1e-9, not to rounding
+    assert np.allclose(mu, omu, rtol=1e-7, atol=1e-10) and abs(sigma - osig) <= 1e-8 * osig
+    assert np.allclose(lp_new, olp, rtol=1e-7, atol=1e-10)

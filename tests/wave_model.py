@@ -293,8 +293,9 @@ def fwd_chain(y, Rf, V, m, T, B, H, c):
         Mprev = _shift_up(Mt, 1, M)
         ref = Mt - q0[tt]
         E0 = np.exp((Mprev + m.sc0) - ref)
-        with np.errstate(under="ignore"):
-            Ea = v * np.exp((s + m.sc0) - ref[None, :])              # v_a * exp(s_a + sc0 - ref)
+        with np.errstate(under="ignore", over="ignore", invalid="ignore"):
+            arg = np.where(v > 0, np.minimum((s + m.sc0) - ref[None, :], 700.0), NEG)   # 0 * exp(big) = NaN
+            Ea = v * np.exp(arg)                                     # v_a * exp(s_a + sc0 - ref)
         al = E0 * m.P00
         be = (Ea * m.PEND[:, None]).sum(0)
         A2, B2 = scan_linear(al, be)
@@ -350,8 +351,8 @@ def bwd_chain(y, Rf, m, T, B, H, c, la0, fv, fref, la0_pre, last=True):
         Mt = np.maximum(Mb + A_, B_)
         Mnext = _shift_up(Mt, 1, Mb)                  # Mb_{t+1}
         E0 = np.exp((Mnext + q1 + m.sc0) - Mt)
-        with np.errstate(under="ignore"):
-            wa = vb * np.exp(sw - Mt[None, :])
+        with np.errstate(under="ignore", over="ignore", invalid="ignore"):
+            wa = vb * np.exp(np.where(vb > 0, np.minimum(sw - Mt[None, :], 700.0), NEG))
         A2, B2 = scan_linear(E0 * m.P00, (wa * m.CP0[:, None]).sum(0))
         xt = A2 * xb + B2
         xnext = _shift_up(xt, 1, xb)
@@ -381,11 +382,11 @@ def bwd_chain(y, Rf, m, T, B, H, c, la0, fv, fref, la0_pre, last=True):
         refb, wa, xt = rec[t]
         la = la0[t] if t >= tc else la0_pre
         if t >= tc:
-            g0[t] = xt * np.exp(la + refb - z)
+            g0[t] = xt * np.exp(min(la + refb - z, 700.0))
         if t + 1 <= tstar:
             with np.errstate(under="ignore"):
-                rho[t + 1] = fv[t + 1] * wa * np.exp(fref[t + 1] + refb - z)
-                xi[t + 1] = wa * np.exp(la + refb - z) if (t >= 0) else np.zeros(N)
+                rho[t + 1] = fv[t + 1] * wa * np.exp(min(fref[t + 1] + refb - z, 700.0))
+                xi[t + 1] = wa * np.exp(min(la + refb - z, 700.0)) if (t >= 0) else np.zeros(N)
     Yn = {t: DLs[t][0] + np.log(DLv[t]) for t in DLv}
     return g0, rho, xi, z, lb0, Yn
 
