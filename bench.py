@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--neurons", type=int, default=4, help="templates (reference N); 4 = headline")
     ap.add_argument("--states", type=int, default=60, help="states per template (reference K)")
+    ap.add_argument("--quick", action="store_true",
+                    help="timed region and per-kernel profile only (no CPU baseline, EM loop, multi-channel, overlap extras): for rocprofv3 runs")
     ap.add_argument("--engine", type=int, default=0, help="0 auto (wave), 2 lane-per-chain ring engine, 4 wave")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--halo", type=int, default=0)
@@ -286,7 +288,7 @@ def main():
         em.close()
         return per * 1e3, float(o[K * N])
     try:
-        em_ms, em_sigma = em_iterations() if not args.time_sharded else (None, None)
+        em_ms, em_sigma = em_iterations() if not (args.time_sharded or args.quick) else (None, None)
     except H.HmmsortError as exc:
         # a template whose firing probability reaches 0 loses its entry transitions (the reference
         # keeps finite entries only, types.jl:121): the list length changes and the plan must be
@@ -318,7 +320,7 @@ def main():
         for pl in plans:
             pl.close()
         return nchan * T / per / 1e6
-    mc = multi_channel(args.channels) if (args.channels > 1 and not args.time_sharded) else None
+    mc = multi_channel(args.channels) if (args.channels > 1 and not args.time_sharded and not args.quick) else None
 
     # ---- overlap-resolving decode: the reference's own Viterbi-test model,
     # test/runtests.jl:17-34 -- 2 templates, K=60, allow_overlaps=true, 3600 states -- through the
@@ -345,7 +347,7 @@ def main():
                 "engine": {1: "strict", 2: "ring", 3: "blocked"}.get(io["engine"], io["engine"]),
                 "block": io["block"], "halo": io["halo"], "Msamples_s": To / per / 1e6,
                 "boundary_check_fails": d[0], "max_boundary_spread": d[2], "near_tie_blocks": d[7]}
-    ov = overlap_decode() if (rank == 0 and world == 1) else None
+    ov = overlap_decode() if (rank == 0 and world == 1 and not args.quick) else None
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -384,7 +386,7 @@ def main():
                        "overlap_decode": ov,
                        "diag": diag[:7], "workspace_GB": info["workspace_bytes"] / 1e9},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.quick:
             res["cpu_baseline"] = cpu_baseline(H, N, K, temps, pp, sigma)
         print(json.dumps(res))
     plan.close()

@@ -53,13 +53,19 @@ struct WaveConst {
     double xishift[kRingMaxN];                 // c0_a - sc_a: log Xi_a = xishift + log Xi'_a
     double cx[kRingMaxN * kRingMaxN];          // [a*N+b]: (a,L) -> (b,1)
     double CPX[kRingMaxN * kRingMaxN];         // [a*N+b] = exp(cx[a,b] - sc_b), 0 on the diagonal
+    double cxin[kRingMaxN];                    // cx[b,a] for any b != a when that is the same for all b (uniform_cx)
+    double CPXin[kRingMaxN];                   // exp(cxin_a - sc_a)
+    double cxT[kRingMaxN * kRingMaxN];         // [b*N+a] = cx[a,b]   (entries INTO ring b, by source ring a)
+    double CPXT[kRingMaxN * kRingMaxN];        // [b*N+a] = CPX[a,b]
 };
 
 struct WaveDev {
     WaveGeom g{};
     bool prof_on = false;
+    bool uniform_cx = true;           // every channel's cx[b,a] is independent of b (bitwise): O(N) junction updates
+    std::vector<char> ucx;            // per channel
     const double *bound_y = nullptr;
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr;
     std::vector<ProfEntry> prof;
     int64_t S = 0, K = 0;
@@ -135,39 +141,90 @@ __device__ __forceinline__ double wave_bcast(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
+// ---- DPP cross-lane moves (gfx9 DPP controls; 2-cycle VALU moves instead of LDS-crossbar permutes) ----
+// row_shr:n = 0x110+n (within rows of 16 lanes), row_bcast:15 = 0x142 (lane 15 of every row to the
+// next row), row_bcast:31 = 0x143 (lane 31 to rows 2 and 3), wave_shr:1 = 0x138.  Lanes without a
+// source (and rows outside row_mask) keep `old`, which the scans set to the identity element.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov(double old, double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROWMASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 // value of lane-1 (lane 0 receives `carry`)
-__device__ __forceinline__ double lane_prev(double v, double carry, int lane)
+__device__ __forceinline__ double lane_prev(double v, double carry)
+{
+    return dpp_mov<0x138, 0xF>(carry, v);
+}
+
+// inclusive scan of f_j(x) = max(x + a_j, b_j) over the 64 lanes: on return f_j o ... o f_0 (x) =
+// max(x + a, b).  Identity element (0, -inf): combining with it is exact, so no lane predicates.
+__device__ __forceinline__ void scan_maxplus(double &a, double &b)
+{
+#define HS_MP_STEP(CTRL, RM)                                                      \
+    {                                                                             \
+        const double al = dpp_mov<CTRL, RM>(0.0, a), bl = dpp_mov<CTRL, RM>(-INFINITY, b); \
+        b = fmax(bl + a, b);                                                      \
+        a = al + a;                                                               \
+    }
+    HS_MP_STEP(0x111, 0xF) HS_MP_STEP(0x112, 0xF) HS_MP_STEP(0x114, 0xF) HS_MP_STEP(0x118, 0xF)
+    HS_MP_STEP(0x142, 0xA) HS_MP_STEP(0x143, 0xC)
+#undef HS_MP_STEP
+}
+
+// inclusive scan of f_j(x) = a_j * x + b_j.  Identity: (1, 0).
+__device__ __forceinline__ void scan_linear(double &a, double &b)
+{
+#define HS_LN_STEP(CTRL, RM)                                                      \
+    {                                                                             \
+        const double al = dpp_mov<CTRL, RM>(1.0, a), bl = dpp_mov<CTRL, RM>(0.0, b); \
+        b = __builtin_fma(a, bl, b);                                              \
+        a = al * a;                                                               \
+    }
+    HS_LN_STEP(0x111, 0xF) HS_LN_STEP(0x112, 0xF) HS_LN_STEP(0x114, 0xF) HS_LN_STEP(0x118, 0xF)
+    HS_LN_STEP(0x142, 0xA) HS_LN_STEP(0x143, 0xC)
+#undef HS_LN_STEP
+}
+
+// shuffle-based references of the three primitives (self-test only: hmmsort_selftest)
+__device__ __forceinline__ double lane_prev_ref(double v, double carry, int lane)
 {
     const double s = __shfl_up(v, 1);
     return lane == 0 ? carry : s;
 }
-
-// inclusive scan of f_j(x) = max(x + a_j, b_j) over the lanes: on return f_j o ... o f_0 (x) =
-// max(x + a, b).  Identity element: (0, -inf).
-__device__ __forceinline__ void scan_maxplus(double &a, double &b, int lane)
+__device__ __forceinline__ void scan_maxplus_ref(double &a, double &b, int lane)
 {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const double al = __shfl_up(a, d), bl = __shfl_up(b, d);
-        if (lane >= d) {
-            b = fmax(bl + a, b);
-            a = al + a;
-        }
+        if (lane >= d) { b = fmax(bl + a, b); a = al + a; }
     }
 }
-
-// inclusive scan of f_j(x) = a_j * x + b_j.  Identity: (1, 0).
-__device__ __forceinline__ void scan_linear(double &a, double &b, int lane)
+__device__ __forceinline__ void scan_linear_ref(double &a, double &b, int lane)
 {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const double al = __shfl_up(a, d), bl = __shfl_up(b, d);
-        if (lane >= d) {
-            b = __builtin_fma(a, bl, b);
-            a = al * a;
-        }
+        if (lane >= d) { b = __builtin_fma(a, bl, b); a = al * a; }
     }
 }
+
+// The model constants are wave-uniform and many (3 + 5N + 2N^2 doubles): left to itself the compiler
+// hoists all their loads out of the sweep loop and spills hundreds of SGPRs into VGPRs.  Passing the
+// table pointer through an empty asm once per super-step keeps them as scalar loads (scalar cache)
+// next to their use.
+__device__ __forceinline__ const WaveConst *reload_consts(const WaveConst *p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// software-pipeline depth of the chain kernels (super-steps of input in flight per wavefront)
+template <int N> constexpr int wave_depth() { return N <= 4 ? 4 : (N <= 8 ? 3 : 2); }
+// register budget of the chain kernels: waves per SIMD the launch bounds ask for
+template <int N> constexpr int wave_occ() { return N <= 4 ? 4 : (N <= 8 ? 2 : 1); }
 
 __device__ __forceinline__ double wave_max(double v)
 {

@@ -41,8 +41,9 @@ static int make_geometry(WaveGeom &g, int64_t T, int C, int N, int L, int64_t bl
     const int64_t m = (H + g.W - 1) / g.W;
     g.Hw = (int)(1 + m * g.W);
     g.He = (int)(m * g.W);
-    // chain length: ~4 wavefronts per SIMD over all channels (1024 SIMDs), at least 2 warm-ups
-    int64_t B = block_req > 0 ? block_req : (T * C + 4095) / 4096;
+    // chain length: 2 wavefronts per SIMD over all channels (1024 SIMDs; the backward sweep holds ~190
+    // VGPRs, and the Viterbi sweep runs beside the forward/backward sweeps), at least 2 warm-ups
+    int64_t B = block_req > 0 ? block_req : (T * C + 2047) / 2048;
     B = std::max<int64_t>(B, std::max<int64_t>(2 * g.Hw, 512));
     if (block_req > 0) B = std::max<int64_t>(block_req, std::max<int64_t>(g.Hw, L + 16));
     B = wround_up(B, 64);
@@ -119,7 +120,25 @@ int wave_set_model(WaveDev *r, int ch, const HostModel &m)
         for (int b = 0; b < N; b++) {
             k.cx[a * N + b] = (a == b) ? -INFINITY : R.cx[a * N + b];
             k.CPX[a * N + b] = (a == b) ? 0.0 : std::exp(R.cx[a * N + b] - k.sc[b]);
+            k.cxT[b * N + a] = k.cx[a * N + b];
+            k.CPXT[b * N + a] = k.CPX[a * N + b];
         }
+    bool ucx = true;
+    for (int a = 0; a < N; a++) {
+        double ref = -INFINITY;
+        bool have = false;
+        for (int b = 0; b < N; b++) {
+            if (b == a) continue;
+            const double v = R.cx[b * N + a];
+            if (!have) { ref = v; have = true; }
+            else if (!(v == ref)) ucx = false;
+        }
+        k.cxin[a] = have ? ref : -INFINITY;
+        k.CPXin[a] = have ? std::exp(ref - k.sc[a]) : 0.0;
+    }
+    r->ucx[ch] = ucx;
+    r->uniform_cx = true;
+    for (char u : r->ucx) r->uniform_cx = r->uniform_cx && u;
     HS_HIP(hipMemcpy(r->d_cst + ch, &k, sizeof(k), hipMemcpyHostToDevice));
     HS_HIP(hipMemcpy(r->d_mean + (size_t)ch * m.S, m.mean.data(), m.S * sizeof(double), hipMemcpyHostToDevice));
     std::vector<double> cint((size_t)N * (L + 1), 0.0), msq((size_t)N * (L + 1), 0.0);
@@ -163,7 +182,7 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
     int rc = make_geometry(r->g, T, C, m.ring.N, m.ring.L, block_req, halo_req);
     if (rc) { delete r; return rc; }
     r->S = m.S; r->K = m.K;
-    r->ring.resize(C); r->mean.resize(C); r->sigma.resize(C);
+    r->ring.resize(C); r->mean.resize(C); r->sigma.resize(C); r->ucx.assign(C, 1);
     const WaveGeom &g = r->g;
     const int64_t N = g.N, L = g.L, CT = (int64_t)C * T, nchT = (int64_t)C * g.nch;
     r->nparts = 1024;
@@ -236,6 +255,7 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
         if (rc) { wave_destroy(r); return rc; }
     }
     if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&r->side2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&r->ev_a, hipEventDisableTiming) != hipSuccess ||
@@ -262,6 +282,7 @@ void wave_destroy(WaveDev *r)
     if (r->ev_a) (void)hipEventDestroy(r->ev_a);
     if (r->ev_b) (void)hipEventDestroy(r->ev_b);
     if (r->side) (void)hipStreamDestroy(r->side);
+    if (r->side2) (void)hipStreamDestroy(r->side2);
     for (auto &e : r->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete r;
 }
@@ -422,6 +443,7 @@ int wave_profile_read(WaveDev *r, hipStream_t st, std::vector<std::string> &name
 {
     HS_HIP(hipStreamSynchronize(st));
     if (r->side) HS_HIP(hipStreamSynchronize(r->side));
+    if (r->side2) HS_HIP(hipStreamSynchronize(r->side2));
     for (auto &e : r->prof) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) { (void)hipGetLastError(); t = 0.f; }
@@ -439,3 +461,36 @@ int wave_profile_read(WaveDev *r, hipStream_t st, std::vector<std::string> &name
 }
 
 }  // namespace hmmsort
+
+// ---- self-test of the cross-lane primitives (DPP scans vs their shuffle references) ---------------
+namespace hmmsort {
+__global__ void kw_selftest_scans(const double *__restrict__ in, double *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    double a = in[lane], b = in[64 + lane], c = in[128 + lane], d = in[192 + lane];
+    double a2 = a, b2 = b, c2 = c, d2 = d;
+    scan_maxplus(a, b);
+    scan_maxplus_ref(a2, b2, lane);
+    scan_linear(c, d);
+    scan_linear_ref(c2, d2, lane);
+    out[lane] = a; out[64 + lane] = b; out[128 + lane] = a2; out[192 + lane] = b2;
+    out[256 + lane] = c; out[320 + lane] = d; out[384 + lane] = c2; out[448 + lane] = d2;
+    out[512 + lane] = lane_prev(in[lane], 123.5);
+    out[576 + lane] = lane_prev_ref(in[lane], 123.5, lane);
+    out[640 + lane] = wave_bcast(in[lane], 63);
+}
+}  // namespace hmmsort
+
+extern "C" int hmmsort_selftest_scans(const double *in256, double *out704)
+{
+    using namespace hmmsort;
+    double *di = nullptr, *dout = nullptr;
+    HS_HIP(hipMalloc((void **)&di, 256 * sizeof(double)));
+    HS_HIP(hipMalloc((void **)&dout, 704 * sizeof(double)));
+    HS_HIP(hipMemcpy(di, in256, 256 * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kw_selftest_scans, dim3(1), dim3(64), 0, nullptr, di, dout);
+    HS_HIP(hipDeviceSynchronize());
+    HS_HIP(hipMemcpy(out704, dout, 704 * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(di); (void)hipFree(dout);
+    return HMMSORT_OK;
+}

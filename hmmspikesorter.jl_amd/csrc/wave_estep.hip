@@ -40,22 +40,38 @@ struct FIn {
     double R[N];
 };
 
+// sum over b != a of t_b * c[b] for every a, O(N): prefix/suffix sums (no subtraction, no cancellation)
+template <int N>
+__device__ __forceinline__ void excl_sums(const double (&t)[N], double (&out)[N])
+{
+    double pre = 0.0;
+#pragma unroll
+    for (int a = 0; a < N; a++) { out[a] = pre; pre += t[a]; }
+    double suf = 0.0;
+#pragma unroll
+    for (int a = N - 1; a >= 0; a--) { out[a] += suf; suf += t[a]; }
+}
+
 // ------------------------------------------------------------------------------------------
 // forward chains (baumwelch.jl:25-51)
+// LDS: constants sc0 | mean0 | den | P00 | einv | sc[N] | CP0[N] | PEND[N] | CPXT[N*N] (UC: CPXin[N]),
+// then the delay line (v_a, s_a) of the last L + W onsets.
 // ------------------------------------------------------------------------------------------
-template <int N>
-__global__ __launch_bounds__(64) void kw_fwd(WaveGeom g, const WaveConst *__restrict__ cst,
-                                             const double *__restrict__ y, const double *__restrict__ Rf,
-                                             const double *__restrict__ virt, double *__restrict__ FA0,
-                                             double *__restrict__ FV, double *__restrict__ FREF,
-                                             double *__restrict__ fpre)
+template <int N, bool UC>
+__global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(WaveGeom g, const WaveConst *__restrict__ cst,
+                                                            const double *__restrict__ y,
+                                                            const double *__restrict__ Rf,
+                                                            const double *__restrict__ virt,
+                                                            double *__restrict__ FA0, double *__restrict__ FV,
+                                                            double *__restrict__ FREF, double *__restrict__ fpre)
 {
+    constexpr int D = wave_depth<N>();
+    constexpr int KSC = 5, KCP0 = 5 + N, KPEND = 5 + 2 * N, KCPX = 5 + 3 * N, KSIZE = 5 + 3 * N + N * N;
     extern __shared__ double lds[];
     const int L = g.L, W = g.W, RB = g.RB, B = g.B;
-    double *DLv = lds, *DLs = lds + N * RB;  // onset t': (v_a, s_a), X_a = s_a + log v_a
+    double *KC = lds, *DLv = lds + KSIZE, *DLs = lds + KSIZE + N * RB;  // onset t': (v_a, s_a), X_a = s_a + log v_a
     const int lane = threadIdx.x;
     const int cg = blockIdx.x, ch = cg / g.nch, c = cg % g.nch;
-    const WaveConst &K = cst[ch];
     const int64_t T = g.T;
     const int64_t tc = (int64_t)c * B;
     const int nc = (int)((T - tc) < B ? (T - tc) : B);
@@ -65,9 +81,15 @@ __global__ __launch_bounds__(64) void kw_fwd(WaveGeom g, const WaveConst *__rest
     double *FAc = FA0 + (int64_t)ch * T, *FRc = FREF + (int64_t)ch * T, *FVc = FV + (int64_t)ch * N * T;
     const int64_t FR = 1 + (int64_t)L * (N + 1);
     double *rec = fpre + cg * FR;
-    const double einv = fexp(-K.sc0);
 
-    for (int i = lane; i < 2 * N * RB; i += 64) lds[i] = 0.0;
+    for (int i = lane; i < 2 * N * RB; i += 64) DLv[i] = 0.0;
+    {
+        const WaveConst &Kg = cst[ch];
+        if (lane == 0) { KC[0] = Kg.sc0; KC[1] = Kg.mean0; KC[2] = Kg.den; KC[3] = Kg.P00; KC[4] = fexp(-Kg.sc0); }
+        if (lane < N) { KC[KSC + lane] = Kg.sc[lane]; KC[KCP0 + lane] = Kg.CP0[lane]; KC[KPEND + lane] = Kg.PEND[lane]; }
+        if (UC) { if (lane < N) KC[KCPX + lane] = Kg.CPXin[lane]; }
+        else for (int i = lane; i < N * N; i += 64) KC[KCPX + i] = Kg.CPXT[i];
+    }
     __syncthreads();
     int64_t tinit;
     double M, x = 1.0;
@@ -80,12 +102,12 @@ __global__ __launch_bounds__(64) void kw_fwd(WaveGeom g, const WaveConst *__rest
                 DLs[a * RB + (L - j)] = virt[((int64_t)ch * N + a) * (L + 1) + j];
             }
         }
-        const double d0 = yc[0] - K.mean0;
-        M = -((d0 * d0) / K.den);
+        const double d0 = yc[0] - KC[1];
+        M = -((d0 * d0) / KC[2]);
         if (lane < N) {
-            const double f0 = fexp(-K.sc[lane]);
+            const double f0 = fexp(-KC[KSC + lane]);
             DLv[lane * RB + L] = f0;
-            DLs[lane * RB + L] = K.sc[lane] + Rc[(int64_t)lane * T];
+            DLs[lane * RB + L] = KC[KSC + lane] + Rc[(int64_t)lane * T];
             FVc[(int64_t)lane * T] = f0;
         }
         if (lane == 0) { FAc[0] = M; FRc[0] = 0.0; }
@@ -98,72 +120,86 @@ __global__ __launch_bounds__(64) void kw_fwd(WaveGeom g, const WaveConst *__rest
     const int n_total = (int)(tend - 1 - tinit);
     auto load = [&](FIn<N> &d, int off) {
         const int nact = n_total - off < W ? n_total - off : W;
-        int64_t t = tinit + 1 + off + (lane < nact ? lane : 0);
-        t = t < T ? t : T - 1;
-        d.y = yc[t];
+        const int li = lane < nact ? lane : 0;
+        int64_t tb = tinit + 1 + off;
+        tb = tb < T ? tb : T - 1;
+        d.y = (yc + tb)[li];
 #pragma unroll
-        for (int a = 0; a < N; a++) d.R[a] = Rc[(int64_t)a * T + t];
+        for (int a = 0; a < N; a++) d.R[a] = (Rc + (int64_t)a * T + tb)[li];
     };
     int rs = (1 + lane) % RB, ws = (L + 1 + lane) % RB;
     auto run = [&](const FIn<N> &d, int off) {
         const int nact = n_total - off < W ? n_total - off : W;
         const bool live = lane < nact;
-        const int64_t t = tinit + 1 + off + lane;
+        const int64_t tb = tinit + 1 + off;
+        const int64_t t = tb + lane;
+        const double sc0 = KC[0];
         double v[N], E[N + 1];
         double e = -INFINITY;
 #pragma unroll
         for (int a = 0; a < N; a++) {
             v[a] = live ? DLv[a * RB + rs] : 0.0;
-            E[a] = DLs[a * RB + rs] + K.sc0;            // scale of the exit of ring a
+            E[a] = DLs[a * RB + rs] + sc0;            // scale of the exit of ring a
             e = fmax(e, scale_of(v[a], E[a]));
         }
-        const double dd = d.y - K.mean0;
-        const double q0 = -((dd * dd) / K.den);
-        double sa = live ? K.sc0 + q0 : 0.0;
+        const double dd = d.y - KC[1];
+        const double q0 = -((dd * dd) / KC[2]);
+        double sa = live ? sc0 + q0 : 0.0;
         double sb = live ? e + q0 : -INFINITY;
-        scan_maxplus(sa, sb, lane);
+        scan_maxplus(sa, sb);
         const double Mt = fmax(M + sa, sb);
-        const double Mprev = lane_prev(Mt, M, lane);
+        const double Mprev = lane_prev(Mt, M);
         const double ref = Mt - q0;
-        E[N] = (Mprev + K.sc0) - ref;
+        E[N] = (Mprev + sc0) - ref;
 #pragma unroll
         for (int a = 0; a < N; a++) E[a] = v[a] > 0.0 ? fmin(E[a] - ref, 700.0) : -INFINITY;  // 0 * exp(big) = NaN
         fexp_n<N + 1>(E);
         const double E0 = E[N];
         double Ea[N];
-        double al = E0 * K.P00, be = 0.0;
+        double al = E0 * KC[3], be = 0.0;
 #pragma unroll
         for (int a = 0; a < N; a++) {
             Ea[a] = v[a] * E[a];
-            be = __builtin_fma(Ea[a], K.PEND[a], be);
+            be = __builtin_fma(Ea[a], KC[KPEND + a], be);
         }
         al = live ? al : 1.0;
         be = live ? be : 0.0;
-        scan_linear(al, be, lane);
+        scan_linear(al, be);
         const double xt = __builtin_fma(al, x, be);
-        const double xprev = lane_prev(xt, x, lane);
+        const double xprev = lane_prev(xt, x);
+        const double einv = KC[4];
         const double base = (xprev * E0) * einv;          // exp(la0(t-1) - ref)
         double u[N];
+        if (UC) {
+            double tb_[N], ex[N];
 #pragma unroll
-        for (int a = 0; a < N; a++) {
-            double su = base * K.CP0[a];
+            for (int a = 0; a < N; a++) tb_[a] = Ea[a] * einv;
+            excl_sums<N>(tb_, ex);
 #pragma unroll
-            for (int b = 0; b < N; b++)
-                if (b != a) su = __builtin_fma(Ea[b] * einv, K.CPX[b * N + a], su);
-            u[a] = su;
+            for (int a = 0; a < N; a++) u[a] = __builtin_fma(ex[a], KC[KCPX + a], base * KC[KCP0 + a]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < N; a++) {
+                double su = base * KC[KCP0 + a];
+#pragma unroll
+                for (int b = 0; b < N; b++)
+                    if (b != a) su = __builtin_fma(Ea[b] * einv, KC[KCPX + a * N + b], su);
+                u[a] = su;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (live) {
 #pragma unroll
             for (int a = 0; a < N; a++) {
                 DLv[a * RB + ws] = u[a];
-                DLs[a * RB + ws] = (ref + K.sc[a]) + d.R[a];
+                DLs[a * RB + ws] = (ref + KC[KSC + a]) + d.R[a];
             }
             const double la0 = Mt + flog(xt);
             if (t >= tc) {
-                FAc[t] = la0;
-                FRc[t] = ref;
+                (FAc + tb)[lane] = la0;
+                (FRc + tb)[lane] = ref;
 #pragma unroll
-                for (int a = 0; a < N; a++) FVc[(int64_t)a * T + t] = u[a];
+                for (int a = 0; a < N; a++) (FVc + (int64_t)a * T + tb)[lane] = u[a];
             } else if (t >= tc - L) {  // warm-up copy of the boundary state (certificate)
                 const int64_t jj = t - (tc - L);
 #pragma unroll
@@ -179,14 +215,17 @@ __global__ __launch_bounds__(64) void kw_fwd(WaveGeom g, const WaveConst *__rest
         rs += W; rs = rs >= RB ? rs - RB : rs;
         ws += W; ws = ws >= RB ? ws - RB : ws;
     };
-    FIn<N> bufA, bufB;
-    load(bufA, 0);
-    for (int off = 0; off < n_total; off += 2 * W) {
-        load(bufB, off + W);
-        run(bufA, off);
-        if (off + W < n_total) {
-            load(bufA, off + 2 * W);
-            run(bufB, off + W);
+    FIn<N> buf[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) load(buf[i], i * W);
+    for (int off = 0; off < n_total; off += D * W) {
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            const int o = off + i * W;
+            if (o < n_total) {
+                run(buf[i], o);
+                load(buf[i], o + D * W);
+            }
         }
     }
 }
@@ -198,6 +237,7 @@ __global__ __launch_bounds__(64) void kw_fwd(WaveGeom g, const WaveConst *__rest
 // down to tstar = tend-1 (warm-up), fixes the normaliser z there, and sweeps its own samples down to
 // tc-1 (the step at tc-1 yields the posteriors of the onsets at tc).
 // Delay line: Yn(tau) at slot (te-1-tau) mod RB; slots never written hold (1, 0) = "beta = 0".
+// LDS: constants sc0 | mean0 | den | P00 | sc[N] | CP0[N] | PEND[N] | CPX[N*N] (UC: CPXin[N]).
 // ------------------------------------------------------------------------------------------
 template <int N>
 struct BIn {
@@ -207,21 +247,25 @@ struct BIn {
     double fref, la0; // fref(t+1), la0(t)
 };
 
-template <int N>
-__global__ __launch_bounds__(64) void kw_bwd(WaveGeom g, const WaveConst *__restrict__ cst,
-                                             const double *__restrict__ y, const double *__restrict__ Rf,
-                                             const double *__restrict__ FA0, const double *__restrict__ FV,
-                                             const double *__restrict__ FREF, const double *__restrict__ fpre,
-                                             double *__restrict__ rho, double *__restrict__ partS,
-                                             double *__restrict__ Zc, double *__restrict__ bpre,
-                                             double *__restrict__ bown, double *__restrict__ yhead)
+template <int N, bool UC>
+__global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const WaveConst *__restrict__ cst,
+                                                            const double *__restrict__ y,
+                                                            const double *__restrict__ Rf,
+                                                            const double *__restrict__ FA0,
+                                                            const double *__restrict__ FV,
+                                                            const double *__restrict__ FREF,
+                                                            const double *__restrict__ fpre,
+                                                            double *__restrict__ rho, double *__restrict__ partS,
+                                                            double *__restrict__ Zc, double *__restrict__ bpre,
+                                                            double *__restrict__ bown, double *__restrict__ yhead)
 {
+    constexpr int D = N <= 4 ? 3 : 2;
+    constexpr int KSC = 4, KCP0 = 4 + N, KPEND = 4 + 2 * N, KCPX = 4 + 3 * N, KSIZE = 4 + 3 * N + N * N;
     extern __shared__ double lds[];
     const int L = g.L, W = g.W, RB = g.RB, B = g.B;
-    double *DLv = lds, *DLs = lds + N * RB;
+    double *KC = lds, *DLv = lds + KSIZE, *DLs = lds + KSIZE + N * RB;
     const int lane = threadIdx.x;
     const int cg = blockIdx.x, ch = cg / g.nch, c = cg % g.nch;
-    const WaveConst &K = cst[ch];
     const int64_t T = g.T;
     const int64_t tc = (int64_t)c * B;
     const int nc = (int)((T - tc) < B ? (T - tc) : B);
@@ -238,6 +282,13 @@ __global__ __launch_bounds__(64) void kw_bwd(WaveGeom g, const WaveConst *__rest
 
     for (int i = lane; i < N * RB; i += 64) DLv[i] = 1.0;
     for (int i = lane; i < RB; i += 64) DLs[i] = 0.0;
+    {
+        const WaveConst &Kg = cst[ch];
+        if (lane == 0) { KC[0] = Kg.sc0; KC[1] = Kg.mean0; KC[2] = Kg.den; KC[3] = Kg.P00; }
+        if (lane < N) { KC[KSC + lane] = Kg.sc[lane]; KC[KCP0 + lane] = Kg.CP0[lane]; KC[KPEND + lane] = Kg.PEND[lane]; }
+        if (UC) { if (lane < N) KC[KCPX + lane] = Kg.CPXin[lane]; }
+        else for (int i = lane; i < N * N; i += 64) KC[KCPX + i] = Kg.CPX[i];
+    }
     __syncthreads();
 
     double Mb = 0.0, xb = 1.0, z = 0.0;
@@ -248,15 +299,19 @@ __global__ __launch_bounds__(64) void kw_bwd(WaveGeom g, const WaveConst *__rest
     const int n_warm = (int)(te - tend);                 // steps t = te-2 .. tstar
     const int n_total = n_warm + nc;                     // ... then tstar-1 .. tc-1
     // super-step schedule: the first warm-up step may be partial so that the warm-up ends exactly at
-    // tstar; then full steps; the last owned step may be partial
+    // tstar; then full steps; the last owned step may be partial.  start(k) = steps done before step k.
+    const int w0 = n_warm % W ? n_warm % W : W;
+    auto start = [&](int k) { return k == 0 ? 0 : w0 + (k - 1) * W; };
     auto width = [&](int done) {
-        if (done < n_warm) { const int r = (n_warm - done) % W; return r ? r : W; }
+        if (done < n_warm) return done == 0 ? w0 : W;
         return n_total - done < W ? n_total - done : W;
     };
     auto load = [&](BIn<N> &d, int done) {
         const int nact = done < n_total ? width(done) : 0;
-        int64_t t = te - 2 - done - (lane < nact ? lane : 0);
-        t = t < -1 ? -1 : t;
+        const int li = lane < nact ? lane : 0;
+        int64_t tb = te - 2 - done;                      // time of lane 0; lane j handles tb - j
+        tb = tb < -1 ? -1 : tb;
+        const int64_t t = tb - li;
         const int64_t t1 = t + 1 < T ? t + 1 : T - 1;
         const int64_t tz = t < 0 ? 0 : t;
         d.y1 = yc[t1];
@@ -272,55 +327,65 @@ __global__ __launch_bounds__(64) void kw_bwd(WaveGeom g, const WaveConst *__rest
     auto run = [&](const BIn<N> &d, int done) {
         const int nact = width(done);
         const bool live = lane < nact;
-        const int i = done + 1 + lane;                   // step index: t = te-1-i
-        const int64_t t = te - 1 - i;
+        const int64_t t = te - 2 - done - lane;          // step index i = done + 1 + lane, t = te-1-i
         const bool owned = done >= n_warm;               // wave-uniform
         int ws = (done + 1) % RB + lane;                 // (done+1) % RB is wave-uniform
         ws = ws >= RB ? ws - RB : ws;
         int rs = ws - L;
         rs = rs < 0 ? rs + RB : rs;
+        const double sc0 = KC[0];
         double vb[N], E[N + 1];
         const double sbv = DLs[rs];
         double e = -INFINITY;
 #pragma unroll
         for (int a = 0; a < N; a++) {
             vb[a] = live ? DLv[a * RB + rs] : 0.0;
-            E[a] = (sbv + d.R[a]) + K.sc[a];             // sw_a
+            E[a] = (sbv + d.R[a]) + KC[KSC + a];         // sw_a
             e = fmax(e, scale_of(vb[a], E[a]));
         }
-        const double dd = d.y1 - K.mean0;
-        const double q1 = -((dd * dd) / K.den);
-        double sa = live ? q1 + K.sc0 : 0.0;
+        const double dd = d.y1 - KC[1];
+        const double q1 = -((dd * dd) / KC[2]);
+        double sa = live ? q1 + sc0 : 0.0;
         double sb = live ? e : -INFINITY;
-        scan_maxplus(sa, sb, lane);
+        scan_maxplus(sa, sb);
         const double Mt = fmax(Mb + sa, sb);
-        const double Mnext = lane_prev(Mt, Mb, lane);
-        E[N] = ((Mnext + q1) + K.sc0) - Mt;
+        const double Mnext = lane_prev(Mt, Mb);
+        E[N] = ((Mnext + q1) + sc0) - Mt;
 #pragma unroll
         for (int a = 0; a < N; a++) E[a] = vb[a] > 0.0 ? fmin(E[a] - Mt, 700.0) : -INFINITY;
         fexp_n<N + 1>(E);
         const double E0 = E[N];
         double wa[N];
-        double al = E0 * K.P00, be = 0.0;
+        double al = E0 * KC[3], be = 0.0;
 #pragma unroll
         for (int a = 0; a < N; a++) {
             wa[a] = vb[a] * E[a];
-            be = __builtin_fma(wa[a], K.CP0[a], be);
+            be = __builtin_fma(wa[a], KC[KCP0 + a], be);
         }
         al = live ? al : 1.0;
         be = live ? be : 0.0;
-        scan_linear(al, be, lane);
+        scan_linear(al, be);
         const double xt = __builtin_fma(al, xb, be);
-        const double xnext = lane_prev(xt, xb, lane);
+        const double xnext = lane_prev(xt, xb);
         const double base = xnext * E0;
         double yn[N];
+        if (UC) {   // ring a's end -> ring b's first state: CPX[a][b] = q_b for every a != b
+            double tq[N], ex[N];
 #pragma unroll
-        for (int a = 0; a < N; a++) {
-            double su = base * K.PEND[a];
+            for (int b = 0; b < N; b++) tq[b] = wa[b] * KC[KCPX + b];
+            excl_sums<N>(tq, ex);
 #pragma unroll
-            for (int b = 0; b < N; b++)
-                if (b != a) su = __builtin_fma(wa[b], K.CPX[a * N + b], su);
-            yn[a] = su;
+            for (int a = 0; a < N; a++) yn[a] = __builtin_fma(base, KC[KPEND + a], ex[a]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < N; a++) {
+                double su = base * KC[KPEND + a];
+#pragma unroll
+                for (int b = 0; b < N; b++)
+                    if (b != a) su = __builtin_fma(wa[b], KC[KCPX + a * N + b], su);
+                yn[a] = su;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (live) {
 #pragma unroll
@@ -391,7 +456,7 @@ __global__ __launch_bounds__(64) void kw_bwd(WaveGeom g, const WaveConst *__rest
 #pragma unroll
             for (int a = 0; a < N; a++) {
                 const double m = FVc[(int64_t)a * T + tp] * DLv[a * RB + slot];
-                const double s = ((fr + K.sc[a]) + Rc[(int64_t)a * T + tp]) + sbv;
+                const double s = ((fr + KC[KSC + a]) + Rc[(int64_t)a * T + tp]) + sbv;
                 if (on) zmax = fmax(zmax, scale_of(m, s));
             }
         }
@@ -407,7 +472,7 @@ __global__ __launch_bounds__(64) void kw_bwd(WaveGeom g, const WaveConst *__rest
 #pragma unroll
             for (int a = 0; a < N; a++) {
                 mant[a] = FVc[(int64_t)a * T + tp] * DLv[a * RB + slot];
-                sc_[a] = mant[a] > 0.0 ? fmin((((fr + K.sc[a]) + Rc[(int64_t)a * T + tp]) + sbv) - zmax, 700.0) : -INFINITY;
+                sc_[a] = mant[a] > 0.0 ? fmin((((fr + KC[KSC + a]) + Rc[(int64_t)a * T + tp]) + sbv) - zmax, 700.0) : -INFINITY;
             }
             fexp_n<N>(sc_);
 #pragma unroll
@@ -425,27 +490,26 @@ __global__ __launch_bounds__(64) void kw_bwd(WaveGeom g, const WaveConst *__rest
                 const double yv = yc[tstar];
                 s_y2 = __builtin_fma(ga, yv * yv, s_y2);
             }
-            if (c == 0 && tstar == 0) yh[N * L] = Mb + flog(xb);
         }
         __syncthreads();
     };
 
-    BIn<N> bufA, bufB;
-    int done = 0;
+    BIn<N> buf[D];
     if (n_warm == 0) znorm();
-    load(bufA, 0);
-    while (done < n_total) {
-        const int w1 = width(done);
-        load(bufB, done + w1);
-        run(bufA, done);
-        done += w1;
-        if (done == n_warm) znorm();
-        if (done >= n_total) break;
-        const int w2 = width(done);
-        load(bufA, done + w2);
-        run(bufB, done);
-        done += w2;
-        if (done == n_warm) znorm();
+    const int nsteps = n_total <= 0 ? 0 : 1 + (n_total - w0 + W - 1) / W;   // w0 first, then W each
+#pragma unroll
+    for (int i = 0; i < D; i++) load(buf[i], start(i));
+    for (int k0 = 0; k0 < nsteps; k0 += D) {
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            const int k = k0 + i;
+            if (k < nsteps) {
+                const int done = start(k);
+                run(buf[i], done);
+                load(buf[i], start(k + D));
+                if (done + width(done) == n_warm) znorm();
+            }
+        }
     }
     // per-chain partial sums -> partS[cg][2N+3] = sx | ra | s_all s_m s_y2
     double *ps = partS + (int64_t)cg * (2 * N + 3);
@@ -824,14 +888,17 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
     int rowsG = 0;
     int rc = dispatch_N(N, [&](auto n) {
         constexpr int NN = decltype(n)::value;
-        const size_t ldsf = (size_t)2 * NN * g.RB * sizeof(double), ldsb = (size_t)(NN + 1) * g.RB * sizeof(double);
+        const size_t ldsf = ((size_t)2 * NN * g.RB + 5 + 3 * NN + NN * NN) * sizeof(double);
+        const size_t ldsb = ((size_t)(NN + 1) * g.RB + 4 + 3 * NN + NN * NN) * sizeof(double);
+        auto kf = r->uniform_cx ? kw_fwd<NN, true> : kw_fwd<NN, false>;
+        auto kb = r->uniform_cx ? kw_bwd<NN, true> : kw_bwd<NN, false>;
         int rc2;
-        if ((rc2 = wave_lds_attr2(kw_fwd<NN>, ldsf)) || (rc2 = wave_lds_attr2(kw_bwd<NN>, ldsb))) return rc2;
+        if ((rc2 = wave_lds_attr2(kf, ldsf)) || (rc2 = wave_lds_attr2(kb, ldsb))) return rc2;
         { WPROF(r, "kw_fwd", st);
-          hipLaunchKernelGGL((kw_fwd<NN>), dim3(nchT), dim3(64), ldsf, st, g, r->d_cst, d_y, r->Rf, r->virt, r->FA0,
+          hipLaunchKernelGGL(kf, dim3(nchT), dim3(64), ldsf, st, g, r->d_cst, d_y, r->Rf, r->virt, r->FA0,
                              r->FV, r->FREF, r->fpre); }
         { WPROF(r, "kw_bwd", st);
-          hipLaunchKernelGGL((kw_bwd<NN>), dim3(nchT), dim3(64), ldsb, st, g, r->d_cst, d_y, r->Rf, r->FA0, r->FV,
+          hipLaunchKernelGGL(kb, dim3(nchT), dim3(64), ldsb, st, g, r->d_cst, d_y, r->Rf, r->FA0, r->FV,
                              r->FREF, r->fpre, r->rho, r->partS, r->Zc, r->bpre, r->bown, r->yhead); }
         HS_HIP(hipGetLastError());
         // certificate + edge terms beside the statistics kernel
@@ -908,9 +975,14 @@ int wave_decode_estep(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll,
     int rc;
     HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
     if ((rc = wave_prepare(r, d_y, st))) return rc;
-    if ((rc = wave_viterbi_sweep(r, d_y, st))) return rc;
-    if ((rc = wave_viterbi_post(r, d_y, d_x, d_ll, st))) return rc;
-    return wave_estep_sweeps(r, d_y, d_stats, st);
+    HS_HIP(hipEventRecord(r->ev_fork, st));
+    HS_HIP(hipStreamWaitEvent(r->side2, r->ev_fork, 0));
+    if ((rc = wave_viterbi_sweep(r, d_y, r->side2))) return rc;
+    if ((rc = wave_viterbi_post(r, d_y, d_x, d_ll, r->side2))) return rc;
+    HS_HIP(hipEventRecord(r->ev_join, r->side2));
+    if ((rc = wave_estep_sweeps(r, d_y, d_stats, st))) return rc;
+    HS_HIP(hipStreamWaitEvent(st, r->ev_join, 0));
+    return HMMSORT_OK;
 }
 
 }  // namespace hmmsort

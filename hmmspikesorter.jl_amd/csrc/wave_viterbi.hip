@@ -52,20 +52,35 @@ __device__ __forceinline__ double wave_thr(const WaveGeom &g, const WaveConst &K
     return ldexp(16.0 * (double)(g.L + 2), ilogb(mmax) - 52) + 4.0 * kVitTol;
 }
 
-template <int N>
-__global__ __launch_bounds__(64) void kw_vit(WaveGeom g, const WaveConst *__restrict__ cst,
-                                             const double *__restrict__ y, const double *__restrict__ Rf,
-                                             const double *__restrict__ virt,
-                                             const double *__restrict__ ysum, uint32_t *__restrict__ psi,
-                                             double *__restrict__ vpre, double *__restrict__ vend,
-                                             const int32_t *__restrict__ vfail, int redo)
+// UC ("uniform cx"): the log-probability of (b,L) -> (a,1) does not depend on b -- true for every
+// list the reference builds (types.jl:94-113: lp[a] + (N-2) lpz, accumulated in an order in which the
+// source ring only contributes an exact +0.0) and checked bitwise on the host (wave_set_model).  The
+// best ring exit into ring a is then "largest X_b over b != a" + cxin_a: one top-3 pass over the N
+// exits serves all N junctions (O(N) instead of O(N^2) per sample).  Adding the same constant is
+// monotone, so the winner can differ from the reference's candidate-by-candidate scan only by a tie
+// created in rounding; such a decision has a zero margin and is flagged like any other near-tie.
+template <int N, bool UC>
+__global__ __launch_bounds__(64, wave_occ<N>()) void kw_vit(WaveGeom g, const WaveConst *__restrict__ cst,
+                                                            const double *__restrict__ y,
+                                                            const double *__restrict__ Rf,
+                                                            const double *__restrict__ virt,
+                                                            const double *__restrict__ ysum,
+                                                            uint32_t *__restrict__ psi, double *__restrict__ vpre,
+                                                            double *__restrict__ vend,
+                                                            const int32_t *__restrict__ vfail, int redo)
 {
-    constexpr int EB = wpsi_bits_c(N), EPW = wpsi_epw_c(N), PW = wpsi_words_c(N);
-    extern __shared__ double DL[];  // [N][RB] delay line: P_a(t') at slot (t' - tinit + L) mod RB
+    constexpr int EB = wpsi_bits_c(N), EPW = wpsi_epw_c(N), PW = wpsi_words_c(N), D = wave_depth<N>();
+    // Model constants live in LDS next to the delay line: they are wave-uniform and many; as
+    // kernel-argument/global scalars the compiler hoists all their loads out of the sweep loop and spills
+    // hundreds of SGPRs.  An LDS word that the loop's own stores may alias is re-read (broadcast) where
+    // it is used.
+    constexpr int KC0 = 3, KCEND = 3 + N, KCXT = 3 + 2 * N, KSIZE = 3 + 2 * N + N * N;
+    extern __shared__ double lds_vit[];
+    double *KC = lds_vit;           // c00 | mean0 | den | c0[N] | cend[N] | cxT[N*N] (UC: cxin[N] first)
+    double *DL = lds_vit + KSIZE;   // [N][RB] delay line: P_a(t') at slot (t' - tinit + L) mod RB
     const int lane = threadIdx.x;
     const int cg = blockIdx.x, ch = cg / g.nch, c = cg % g.nch;
     if (redo && (c == 0 || vfail[cg] == 0 || vfail[cg - 1] != 0)) return;  // wave-uniform
-    const WaveConst &K = cst[ch];
     const int L = g.L, W = g.W, RB = g.RB, B = g.B;
     const int64_t T = g.T;
     const int64_t tc = (int64_t)c * B;
@@ -73,11 +88,19 @@ __global__ __launch_bounds__(64) void kw_vit(WaveGeom g, const WaveConst *__rest
     const int64_t tend = tc + nc;
     const double *yc = y + (int64_t)ch * T;
     const double *Rc = Rf + (int64_t)ch * N * T;
+    uint32_t *psic = psi + (int64_t)ch * T;
     const int64_t SR = 1 + N * L;
     const int64_t planePsi = (int64_t)g.C * T;
-    const double thr = wave_thr(g, K, ysum, ch);
+    const double thr = wave_thr(g, cst[ch], ysum, ch);
 
     for (int i = lane; i < N * RB; i += 64) DL[i] = -INFINITY;
+    {
+        const WaveConst &Kg = cst[ch];
+        if (lane == 0) { KC[0] = Kg.c00; KC[1] = Kg.mean0; KC[2] = Kg.den; }
+        if (lane < N) { KC[KC0 + lane] = Kg.c0[lane]; KC[KCEND + lane] = Kg.cend[lane]; }
+        if (UC) { if (lane < N) KC[KCXT + lane] = Kg.cxin[lane]; }
+        else for (int i = lane; i < N * N; i += 64) KC[KCXT + i] = Kg.cxT[i];
+    }
     __syncthreads();
     int64_t tinit;
     double D0;
@@ -90,7 +113,7 @@ __global__ __launch_bounds__(64) void kw_vit(WaveGeom g, const WaveConst *__rest
         }
     } else if (c == 0) {   // the reference's first column (viterbi.jl:55-63): emission only, T1[1,1] = 0
         tinit = 0;
-        D0 = -K.A;
+        D0 = -cst[ch].A;
         for (int i = lane; i < N * L; i += 64) {
             const int a = i / L, j = i % L + 1;  // virtual onset -j -> slot L - j
             DL[a * RB + (L - j)] = virt[((int64_t)ch * N + a) * (L + 1) + j];
@@ -103,82 +126,106 @@ __global__ __launch_bounds__(64) void kw_vit(WaveGeom g, const WaveConst *__rest
     __syncthreads();
 
     const int n_total = (int)(tend - 1 - tinit);  // steps t = tinit+1 .. tend-1
+    // inputs of the super-step that starts `off` steps into the sweep: uniform base + lane offset
     auto load = [&](WIn<N> &d, int off) {
         const int nact = n_total - off < W ? n_total - off : W;
-        int64_t t = tinit + 1 + off + (lane < nact ? lane : 0);
-        t = t < T ? t : T - 1;
-        d.y = yc[t];
+        const int li = lane < nact ? lane : 0;
+        int64_t tb = tinit + 1 + off;
+        tb = tb < T ? tb : T - 1;
+        d.y = (yc + tb)[li];
 #pragma unroll
-        for (int a = 0; a < N; a++) d.R[a] = Rc[(int64_t)a * T + t];
+        for (int a = 0; a < N; a++) d.R[a] = (Rc + (int64_t)a * T + tb)[li];
     };
     int rs = (1 + lane) % RB, ws = (L + 1 + lane) % RB;
     auto run = [&](const WIn<N> &d, int off) {
         const int nact = n_total - off < W ? n_total - off : W;
         const bool live = lane < nact;
-        const int64_t t = tinit + 1 + off + lane;
+        const int64_t tb = tinit + 1 + off;
         double X[N];
 #pragma unroll
         for (int a = 0; a < N; a++) {
             const double v = DL[a * RB + rs];
             X[a] = live ? v : -INFINITY;
         }
-        // ring exits into the silent state: best and runner-up among the rings
+        // ring exits into the silent state: best and runner-up among the rings (first maximum wins)
         double e1 = -INFINITY, e2 = -INFINITY;
         int earg = 0;
 #pragma unroll
         for (int a = 0; a < N; a++) {
-            const double v = X[a] + K.cend[a];
-            if (v > e1) { e2 = e1; e1 = v; earg = a + 1; }
-            else e2 = fmax(e2, v);
+            const double v = X[a] + KC[KCEND + a];
+            earg = v > e1 ? a + 1 : earg;
+            e2 = fmax(e2, fmin(e1, v));
+            e1 = fmax(e1, v);
         }
-        const double dd = d.y - K.mean0;
-        const double q0 = -((dd * dd) / K.den);
-        double sa = live ? K.c00 + q0 : 0.0;
+        const double c00 = KC[0];
+        const double dd = d.y - KC[1];
+        const double q0 = -((dd * dd) / KC[2]);
+        double sa = live ? c00 + q0 : 0.0;
         double sb = live ? e1 + q0 : -INFINITY;
-        scan_maxplus(sa, sb, lane);
-        const double D = fmax(D0 + sa, sb);
-        const double Dprev = lane_prev(D, D0, lane);
+        scan_maxplus(sa, sb);
+        const double Dn = fmax(D0 + sa, sb);
+        const double Dprev = lane_prev(Dn, D0);
         uint32_t pw[PW];
 #pragma unroll
         for (int w = 0; w < PW; w++) pw[w] = 0u;
         {
-            const double v0 = Dprev + K.c00;
+            const double v0 = Dprev + c00;
             const bool ring = e1 > v0;
-            const double best = ring ? e1 : v0;
-            const double sec = ring ? fmax(e2, v0) : e1;
-            const uint32_t fl = (best - sec) < thr ? 1u : 0u;
+            const double gap = ring ? e1 - fmax(e2, v0) : v0 - e1;
+            const uint32_t fl = gap < thr ? 1u : 0u;
             pw[0] = (ring ? (uint32_t)earg : 0u) | (fl << (EB - 1));
         }
-        double Pn[N];
+        // top three exits (first index wins ties) for the UC path
+        double m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+        int i1 = 0, i2 = 0;
+        if (UC) {
+#pragma unroll
+            for (int b = 0; b < N; b++) {
+                const double v = X[b];
+                const bool g1 = v > m1, g2 = v > m2;
+                m3 = g2 ? m2 : fmax(m3, v);
+                i2 = g1 ? i1 : (g2 ? b + 1 : i2);
+                m2 = g1 ? m1 : (g2 ? v : m2);
+                i1 = g1 ? b + 1 : i1;
+                m1 = g1 ? v : m1;
+            }
+        }
 #pragma unroll
         for (int a = 0; a < N; a++) {
             double r1 = -INFINITY, r2 = -INFINITY;
             int rarg = 0;
+            if (UC) {
+                const double cin = KC[KCXT + a];
+                const bool first = (a + 1 == i1), second = (a + 1 == i2);
+                r1 = (first ? m2 : m1) + cin;
+                rarg = first ? i2 : i1;
+                r2 = ((first || second) ? m3 : m2) + cin;
+                if (N == 1) { r1 = -INFINITY; r2 = -INFINITY; rarg = 0; }
+            } else {
 #pragma unroll
-            for (int b = 0; b < N; b++) {
-                if (b == a) continue;
-                const double v = X[b] + K.cx[b * N + a];
-                if (v > r1) { r2 = r1; r1 = v; rarg = b + 1; }
-                else r2 = fmax(r2, v);
+                for (int b = 0; b < N; b++) {
+                    if (b == a) continue;
+                    const double v = X[b] + KC[KCXT + a * N + b];   // (b,L) -> (a,1)
+                    rarg = v > r1 ? b + 1 : rarg;
+                    r2 = fmax(r2, fmin(r1, v));
+                    r1 = fmax(r1, v);
+                }
             }
-            const double v0 = Dprev + K.c0[a];
+            const double v0 = Dprev + KC[KC0 + a];
             const bool ring = r1 > v0;
             const double u = ring ? r1 : v0;
-            const double sec = ring ? fmax(r2, v0) : r1;
-            const uint32_t fl = (u - sec) < thr ? 1u : 0u;
-            Pn[a] = u + d.R[a];
+            const double gap = ring ? r1 - fmax(r2, v0) : v0 - r1;
+            const uint32_t fl = gap < thr ? 1u : 0u;
+            if (live) DL[a * RB + ws] = u + d.R[a];
             const uint32_t ent = (ring ? (uint32_t)rarg : 0u) | (fl << (EB - 1));
             pw[(a + 1) / EPW] |= ent << (((a + 1) % EPW) * EB);
+            if (!UC) __builtin_amdgcn_sched_barrier(0);   // keep the junctions sequential: N^2 live candidates otherwise
         }
-        if (live) {
+        if (live && tb + lane >= tc) {
 #pragma unroll
-            for (int a = 0; a < N; a++) DL[a * RB + ws] = Pn[a];
-            if (t >= tc) {
-#pragma unroll
-                for (int w = 0; w < PW; w++) psi[w * planePsi + (int64_t)ch * T + t] = pw[w];
-            }
+            for (int w = 0; w < PW; w++) (psic + w * planePsi + tb)[lane] = pw[w];
         }
-        D0 = wave_bcast(D, 63);  // idle lanes carry the identity, so lane 63 holds the last live value
+        D0 = wave_bcast(Dn, 63);  // idle lanes carry the identity, so lane 63 holds the last live value
         rs += W; rs = rs >= RB ? rs - RB : rs;
         ws += W; ws = ws >= RB ? ws - RB : ws;
     };
@@ -193,17 +240,20 @@ __global__ __launch_bounds__(64) void kw_vit(WaveGeom g, const WaveConst *__rest
         __syncthreads();
     };
 
-    WIn<N> bufA, bufB;
+    // D super-steps of input in flight; the ring of buffers is indexed statically
+    WIn<N> buf[D];
     const int n_warm = (redo || c == 0) ? -1 : g.Hw - 1;
-    load(bufA, 0);
-    for (int off = 0; off < n_total; off += 2 * W) {
-        load(bufB, off + W);
-        run(bufA, off);
-        if (off + W == n_warm) dump(vpre + cg * SR, tc);
-        if (off + W < n_total) {
-            load(bufA, off + 2 * W);
-            run(bufB, off + W);
-            if (off + 2 * W == n_warm) dump(vpre + cg * SR, tc);
+#pragma unroll
+    for (int i = 0; i < D; i++) load(buf[i], i * W);
+    for (int off = 0; off < n_total; off += D * W) {
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            const int o = off + i * W;
+            if (o < n_total) {
+                run(buf[i], o);
+                load(buf[i], o + D * W);
+                if (o + W == n_warm) dump(vpre + cg * SR, tc);
+            }
         }
     }
     dump(vend + cg * SR, tend);
@@ -547,11 +597,12 @@ int wave_viterbi_sweep(WaveDev *r, const double *d_y, hipStream_t st)
     const int nchT = g.C * g.nch;
     return dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
-        const size_t lds = (size_t)N * g.RB * sizeof(double);
-        int rc = wave_lds_attr(kw_vit<N>, lds);
+        const size_t lds = ((size_t)N * g.RB + 3 + 2 * N + N * N) * sizeof(double);
+        auto kern = r->uniform_cx ? kw_vit<N, true> : kw_vit<N, false>;
+        int rc = wave_lds_attr(kern, lds);
         if (rc) return rc;
         { WPROF(r, "kw_vit", st);
-          hipLaunchKernelGGL((kw_vit<N>), dim3(nchT), dim3(64), lds, st, g, r->d_cst, d_y, r->Rf, r->virt, r->ysum,
+          hipLaunchKernelGGL(kern, dim3(nchT), dim3(64), lds, st, g, r->d_cst, d_y, r->Rf, r->virt, r->ysum,
                              r->psi, r->vpre, r->vend, r->vfail, 0); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
@@ -565,12 +616,13 @@ int wave_viterbi_post(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll,
     const int nchT = g.C * g.nch;
     int rc = dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
-        const size_t lds = (size_t)N * g.RB * sizeof(double);
+        const size_t lds = ((size_t)N * g.RB + 3 + 2 * N + N * N) * sizeof(double);
+        auto kern = r->uniform_cx ? kw_vit<N, true> : kw_vit<N, false>;
         for (int round = 0; round < kVitRounds && g.nch > 1; round++) {
             { WPROF(r, "kw_vit_check", st);
               hipLaunchKernelGGL(kw_vit_check, dim3(nchT), dim3(64), 0, st, g, r->vpre, r->vend, r->vfail, r->diag, 0); }
             { WPROF(r, "kw_vit_redo", st);
-              hipLaunchKernelGGL((kw_vit<N>), dim3(nchT), dim3(64), lds, st, g, r->d_cst, d_y, r->Rf, r->virt,
+              hipLaunchKernelGGL(kern, dim3(nchT), dim3(64), lds, st, g, r->d_cst, d_y, r->Rf, r->virt,
                                  r->ysum, r->psi, r->vpre, r->vend, r->vfail, 1); }
         }
         { WPROF(r, "kw_vit_check", st);

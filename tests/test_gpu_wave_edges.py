@@ -103,3 +103,34 @@ def test_large_amplitude_and_tiny_sigma(O, H):
     smn, mun, sgn = H.train_step(y, sm, mu.copy(order="F"), 0.08)
     osmn, omu, osig, olp, opp = O.train_step(y, osm, mu.copy(order="F"), 0.08)
     assert np.allclose(mun, omu, rtol=1e-7, atol=1e-10) and abs(sgn - osig) <= 1e-7 * osig
+
+
+def test_dpp_scans_match_shuffle_references(H):
+    """the cross-lane primitives of the wave engine (DPP row_shr / row_bcast / wave_shr moves) against
+    their shuffle-based references and against numpy"""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    inp = np.concatenate([rng.normal(-1, 2, 64), rng.normal(0, 5, 64), rng.uniform(0.2, 1.0, 64),
+                          rng.uniform(0, 2, 64)])
+    inp[64 + 7] = -np.inf
+    out = np.zeros(704)
+    fn = H._lib.lib().hmmsort_selftest_scans
+    fn.argtypes = [C.c_void_p, C.c_void_p]
+    fn.restype = C.c_int
+    assert fn(inp.ctypes.data, out.ctypes.data) == 0
+    a, b, a2, b2, c, d, c2, d2 = [out[64 * i:64 * i + 64] for i in range(8)]
+    # same function, different association order of the 64-lane scan (rows of 16 first): equal to rounding
+    for u, v in ((a, a2), (b, b2), (c, c2), (d, d2)):
+        assert np.allclose(u, v, rtol=1e-13, atol=1e-13)
+    # sequential semantics: f_j(x) = max(x + a_j, b_j) composed over j = 0..i
+    x = -3.25
+    for i in range(64):
+        x = max(x + inp[i], inp[64 + i])
+        assert abs(max(-3.25 + a[i], b[i]) - x) <= 1e-12 * max(1.0, abs(x))
+    x = 0.75
+    for i in range(64):
+        x = inp[128 + i] * x + inp[192 + i]
+        assert abs((c[i] * 0.75 + d[i]) - x) <= 1e-12 * max(1.0, abs(x))
+    assert np.array_equal(out[512:576], out[576:640])
+    assert out[512] == 123.5 and np.array_equal(out[513:576], inp[:63])
+    assert np.all(out[640:704] == inp[63])
