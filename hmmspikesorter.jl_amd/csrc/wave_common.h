@@ -103,6 +103,7 @@ struct WaveDev {
     double *extra = nullptr;          // C x 3*N*L
     double *pp = nullptr;             // C x S
     int64_t *diag = nullptr;          // 8
+    double *trash = nullptr;          // 64 x 64 doubles: where idle lanes of a partial super-step store (branch-free stores)
     double *dbg = nullptr;            // 64 doubles: debug record of the first failing certificate
     int64_t bytes = 0;
     int nparts = 0, gparts = 0;

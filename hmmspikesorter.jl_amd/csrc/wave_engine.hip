@@ -221,6 +221,7 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
     A(&r->pp, C * m.S);
     A(&r->diag, 8);
     A(&r->dbg, 64);
+    A(&r->trash, 64 * 64);
     if (!ok) { wave_destroy(r); return HMMSORT_ENOMEM; }
     if (getenv("HMMSORT_POISON")) {  // test aid: NaN bit patterns in everything a kernel might read unwritten
         (void)hipMemset(r->Rf, 0xFF, N * CT * 8);
@@ -274,7 +275,7 @@ void wave_destroy(WaveDev *r)
     void *ptrs[] = {r->d_cst, r->d_mean, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->Rf, r->virt, r->ysum,
                     r->psi, r->vpre, r->vend, r->vfail, r->bstate, r->redo, r->final_state, r->part, r->FA0,
                     r->FV, r->FREF, r->fpre, r->bpre, r->bown, r->rho, r->Zc, r->partS, r->partG, r->yhead,
-                    r->extra, r->pp, r->diag, r->dbg};
+                    r->extra, r->pp, r->diag, r->dbg, r->trash};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
@@ -301,11 +302,11 @@ int64_t wave_stats_len(const WaveDev *r) { return 3 * (int64_t)r->g.N * r->g.L +
 //   Rf[ch][a][t'] = Cint[a][kmax] - (sum_k y^2 - 2 sum_k y*mean(a,k) + Msq[a][kmax]) / den,
 //   kmax = min(L, T - t')  (rings running off the end of the data are truncated: the reference's
 //   terminal conditions, viterbi.jl:90 / baumwelch.jl:80); y beyond the end counts as 0.
-// Block = 256 threads x 4 onsets; the y tile is staged in LDS once, means are wave-uniform.
+// Block = 256 threads x 8 onsets; the y tile and the means are staged in LDS once (means read as broadcasts).
 // Also accumulates sum y and sum y^2 per channel (magnitude of the reference's trellis, for the
 // near-tie threshold of the Viterbi sweep).
 // ------------------------------------------------------------------------------------------
-constexpr int kPreTile = 1024;
+template <int N> constexpr int pre_rows() { return N <= 4 ? 8 : (N <= 8 ? 4 : 2); }
 
 template <int N>
 __global__ __launch_bounds__(256) void kw_prepass(WaveGeom g, const WaveConst *__restrict__ cst,
@@ -315,31 +316,35 @@ __global__ __launch_bounds__(256) void kw_prepass(WaveGeom g, const WaveConst *_
                                                   const double *__restrict__ msq,
                                                   double *__restrict__ Rf, double *__restrict__ ysum)
 {
-    extern __shared__ double ly[];  // kPreTile + L
+    constexpr int kPreRows = pre_rows<N>(), kPreTile = 256 * kPreRows;
+    extern __shared__ double ly[];  // y tile: kPreTile + L | means: N*L (read as broadcasts)
     __shared__ double red[8];
     const int ch = blockIdx.y, L = g.L, S = 1 + N * L;
     const int64_t T = g.T, t0 = (int64_t)blockIdx.x * kPreTile;
     const double *yc = y + (int64_t)ch * T;
     const double *mc = mean + (int64_t)ch * S;
+    double *lm = ly + kPreTile + L;
     for (int i = threadIdx.x; i < kPreTile + L; i += 256) {
         const int64_t t = t0 + i;
         const double v = yc[t < T ? t : T - 1];
         ly[i] = t < T ? v : 0.0;
     }
+    for (int i = threadIdx.x; i < N * L; i += 256) lm[i] = mc[1 + i];
     __syncthreads();
-    double dot[4][N], ysq[4];
+    double dot[kPreRows][N], ysq[kPreRows];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < kPreRows; r++) {
         ysq[r] = 0.0;
 #pragma unroll
         for (int a = 0; a < N; a++) dot[r][a] = 0.0;
     }
+#pragma unroll 2
     for (int k = 0; k < L; k++) {
         double mv[N];
 #pragma unroll
-        for (int a = 0; a < N; a++) mv[a] = mc[1 + a * L + k];
+        for (int a = 0; a < N; a++) mv[a] = lm[a * L + k];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < kPreRows; r++) {
             const double yv = ly[threadIdx.x + 256 * r + k];
             ysq[r] = __builtin_fma(yv, yv, ysq[r]);
 #pragma unroll
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(256) void kw_prepass(WaveGeom g, const WaveConst *_
     const double den = cst[ch].den;
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < kPreRows; r++) {
         const int64_t t = t0 + threadIdx.x + 256 * r;
         if (t < T) {
             const int64_t rem = T - t;
@@ -416,8 +421,9 @@ int wave_prepare(WaveDev *r, const double *d_y, hipStream_t st)
     int rc = dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
         WPROF(r, "kw_prepass", st);
+        constexpr int kPreTile = 256 * pre_rows<N>();
         hipLaunchKernelGGL((kw_prepass<N>), dim3((unsigned)((g.T + kPreTile - 1) / kPreTile), g.C), dim3(256),
-                           (size_t)(kPreTile + g.L) * sizeof(double), st, g, r->d_cst, d_y, r->d_mean, r->d_cint,
+                           (size_t)(kPreTile + g.L + N * g.L) * sizeof(double), st, g, r->d_cst, d_y, r->d_mean, r->d_cint,
                            r->d_msq, r->Rf, r->ysum);
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;

@@ -63,13 +63,14 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
                                                             const double *__restrict__ Rf,
                                                             const double *__restrict__ virt,
                                                             double *__restrict__ FA0, double *__restrict__ FV,
-                                                            double *__restrict__ FREF, double *__restrict__ fpre)
+                                                            double *__restrict__ FREF, double *__restrict__ fpre,
+                                                            double *__restrict__ trash)
 {
     constexpr int D = wave_depth<N>();
     constexpr int KSC = 5, KCP0 = 5 + N, KPEND = 5 + 2 * N, KCPX = 5 + 3 * N, KSIZE = 5 + 3 * N + N * N;
     extern __shared__ double lds[];
     const int L = g.L, W = g.W, RB = g.RB, B = g.B;
-    double *KC = lds, *DLv = lds + KSIZE, *DLs = lds + KSIZE + N * RB;  // onset t': (v_a, s_a), X_a = s_a + log v_a
+    double *KC = lds, *DLv = lds + KSIZE, *DLs = lds + KSIZE + N * (RB + 1);  // onset t': (v_a, s_a), X_a = s_a + log v_a; row stride RB+1 (spare slot)
     const int lane = threadIdx.x;
     const int cg = blockIdx.x, ch = cg / g.nch, c = cg % g.nch;
     const int64_t T = g.T;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
     const int64_t FR = 1 + (int64_t)L * (N + 1);
     double *rec = fpre + cg * FR;
 
-    for (int i = lane; i < 2 * N * RB; i += 64) DLv[i] = 0.0;
+    for (int i = lane; i < 2 * N * (RB + 1); i += 64) DLv[i] = 0.0;
     {
         const WaveConst &Kg = cst[ch];
         if (lane == 0) { KC[0] = Kg.sc0; KC[1] = Kg.mean0; KC[2] = Kg.den; KC[3] = Kg.P00; KC[4] = fexp(-Kg.sc0); }
@@ -98,16 +99,16 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
         for (int i = lane; i < N * L; i += 64) {
             const int a = i / L, j = i % L + 1;
             if (j < L) {
-                DLv[a * RB + (L - j)] = 1.0;
-                DLs[a * RB + (L - j)] = virt[((int64_t)ch * N + a) * (L + 1) + j];
+                DLv[a * (RB + 1) + (L - j)] = 1.0;
+                DLs[a * (RB + 1) + (L - j)] = virt[((int64_t)ch * N + a) * (L + 1) + j];
             }
         }
         const double d0 = yc[0] - KC[1];
         M = -((d0 * d0) / KC[2]);
         if (lane < N) {
             const double f0 = fexp(-KC[KSC + lane]);
-            DLv[lane * RB + L] = f0;
-            DLs[lane * RB + L] = KC[KSC + lane] + Rc[(int64_t)lane * T];
+            DLv[lane * (RB + 1) + L] = f0;
+            DLs[lane * (RB + 1) + L] = KC[KSC + lane] + Rc[(int64_t)lane * T];
             FVc[(int64_t)lane * T] = f0;
         }
         if (lane == 0) { FAc[0] = M; FRc[0] = 0.0; }
@@ -128,7 +129,12 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
         for (int a = 0; a < N; a++) d.R[a] = (Rc + (int64_t)a * T + tb)[li];
     };
     int rs = (1 + lane) % RB, ws = (L + 1 + lane) % RB;
-    auto run = [&](const FIn<N> &d, int off) {
+    // MODE 0: warm-up super-step, no global stores; 1: owned super-step, every lane stores (idle lanes of
+    // the last partial step into a trash line); 2: the last super-steps of the warm-up, which also leave
+    // the boundary record (conditional stores).  Modes 0 and 1 have straight-line global accesses only,
+    // so hipcc counts vmcnt exactly and the input pipeline stays D super-steps deep.
+    auto run = [&](const FIn<N> &d, int off, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
         const int nact = n_total - off < W ? n_total - off : W;
         const bool live = lane < nact;
         const int64_t tb = tinit + 1 + off;
@@ -138,8 +144,8 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
         double e = -INFINITY;
 #pragma unroll
         for (int a = 0; a < N; a++) {
-            v[a] = live ? DLv[a * RB + rs] : 0.0;
-            E[a] = DLs[a * RB + rs] + sc0;            // scale of the exit of ring a
+            v[a] = live ? DLv[a * (RB + 1) + rs] : 0.0;
+            E[a] = DLs[a * (RB + 1) + rs] + sc0;            // scale of the exit of ring a
             e = fmax(e, scale_of(v[a], E[a]));
         }
         const double dd = d.y - KC[1];
@@ -188,24 +194,26 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (live) {
+        const int wsl = live ? ws : RB;   // idle lanes write the spare slot behind the ring
 #pragma unroll
-            for (int a = 0; a < N; a++) {
-                DLv[a * RB + ws] = u[a];
-                DLs[a * RB + ws] = (ref + KC[KSC + a]) + d.R[a];
-            }
+        for (int a = 0; a < N; a++) {
+            DLv[a * (RB + 1) + wsl] = u[a];
+            DLs[a * (RB + 1) + wsl] = (ref + KC[KSC + a]) + d.R[a];
+        }
+        if (MODE == 1) {
             const double la0 = Mt + flog(xt);
-            if (t >= tc) {
-                (FAc + tb)[lane] = la0;
-                (FRc + tb)[lane] = ref;
+            *(live ? FAc + tb + lane : trash + lane) = la0;
+            *(live ? FRc + tb + lane : trash + 64 + lane) = ref;
 #pragma unroll
-                for (int a = 0; a < N; a++) (FVc + (int64_t)a * T + tb)[lane] = u[a];
-            } else if (t >= tc - L) {  // warm-up copy of the boundary state (certificate)
+            for (int a = 0; a < N; a++) *(live ? FVc + (int64_t)a * T + tb + lane : trash + 64 * (2 + a) + lane) = u[a];
+        }
+        if (MODE == 2) {
+            if (live && t >= tc - L && t < tc) {  // warm-up copy of the boundary state (certificate)
                 const int64_t jj = t - (tc - L);
 #pragma unroll
                 for (int a = 0; a < N; a++) rec[1 + jj * (N + 1) + a] = u[a];
                 rec[1 + jj * (N + 1) + N] = ref;
-                if (t == tc - 1) rec[0] = la0;
+                if (t == tc - 1) rec[0] = Mt + flog(xt);
             }
         }
         x = wave_bcast(xt, 63);
@@ -215,19 +223,30 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
         rs += W; rs = rs >= RB ? rs - RB : rs;
         ws += W; ws = ws >= RB ? ws - RB : ws;
     };
-    FIn<N> buf[D];
+    // The main loop is branch-free (whole groups of D super-steps, loads clamped past the end), so that
+    // hipcc can count vmcnt across the back edge; the last < D super-steps run from the buffers the main
+    // loop has already filled.
+    auto sweep = [&](int from, int to, auto mode_tag) {
+        FIn<N> buf[D];
 #pragma unroll
-    for (int i = 0; i < D; i++) load(buf[i], i * W);
-    for (int off = 0; off < n_total; off += D * W) {
+        for (int i = 0; i < D; i++) load(buf[i], from + i * W);
+        int off = from;
+        for (; off + D * W <= to; off += D * W) {
 #pragma unroll
-        for (int i = 0; i < D; i++) {
-            const int o = off + i * W;
-            if (o < n_total) {
-                run(buf[i], o);
-                load(buf[i], o + D * W);
+            for (int i = 0; i < D; i++) {
+                run(buf[i], off + i * W, mode_tag);
+                load(buf[i], off + (i + D) * W);
             }
         }
-    }
+#pragma unroll
+        for (int i = 0; i < D; i++)
+            if (off + i * W < to) run(buf[i], off + i * W, mode_tag);
+    };
+    const int n_warm = c == 0 ? 0 : g.Hw - 1;                     // multiple of W
+    const int n_rec = ((L + W - 1) / W) * W < n_warm ? ((L + W - 1) / W) * W : n_warm;
+    if (n_warm - n_rec > 0) sweep(0, n_warm - n_rec, std::integral_constant<int, 0>());
+    if (n_rec > 0) sweep(n_warm - n_rec, n_warm, std::integral_constant<int, 2>());
+    sweep(n_warm, n_total, std::integral_constant<int, 1>());
 }
 
 // ------------------------------------------------------------------------------------------
@@ -257,13 +276,14 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
                                                             const double *__restrict__ fpre,
                                                             double *__restrict__ rho, double *__restrict__ partS,
                                                             double *__restrict__ Zc, double *__restrict__ bpre,
-                                                            double *__restrict__ bown, double *__restrict__ yhead)
+                                                            double *__restrict__ bown, double *__restrict__ yhead,
+                                                            double *__restrict__ trash)
 {
-    constexpr int D = N <= 4 ? 3 : 2;
+    constexpr int D = N <= 4 ? 3 : (N <= 8 ? 2 : 1);
     constexpr int KSC = 4, KCP0 = 4 + N, KPEND = 4 + 2 * N, KCPX = 4 + 3 * N, KSIZE = 4 + 3 * N + N * N;
     extern __shared__ double lds[];
     const int L = g.L, W = g.W, RB = g.RB, B = g.B;
-    double *KC = lds, *DLv = lds + KSIZE, *DLs = lds + KSIZE + N * RB;
+    double *KC = lds, *DLv = lds + KSIZE, *DLs = lds + KSIZE + N * (RB + 1);   // row stride RB+1: spare slot
     const int lane = threadIdx.x;
     const int cg = blockIdx.x, ch = cg / g.nch, c = cg % g.nch;
     const int64_t T = g.T;
@@ -280,8 +300,8 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
     double *recp = bpre + cg * FR, *reco = bown + cg * FR;
     double *yh = yhead + (int64_t)ch * (N * L + 2);
 
-    for (int i = lane; i < N * RB; i += 64) DLv[i] = 1.0;
-    for (int i = lane; i < RB; i += 64) DLs[i] = 0.0;
+    for (int i = lane; i < N * (RB + 1); i += 64) DLv[i] = 1.0;
+    for (int i = lane; i < RB + 1; i += 64) DLs[i] = 0.0;
     {
         const WaveConst &Kg = cst[ch];
         if (lane == 0) { KC[0] = Kg.sc0; KC[1] = Kg.mean0; KC[2] = Kg.den; KC[3] = Kg.P00; }
@@ -324,11 +344,17 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
             d.fv[a] = FVc[(int64_t)a * T + t1];
         }
     };
-    auto run = [&](const BIn<N> &d, int done) {
+    // MODE 0: warm-up super-step (recursion only, no global stores); 1: owned super-step (posteriors; every
+    // lane stores rho, idle lanes of a partial step into a trash line); 2: the last super-steps of the
+    // warm-up and of the chain's own samples, which also leave the boundary records and the head of the
+    // recording (conditional stores).  Modes 0 and 1 keep global accesses straight-line (exact vmcnt).
+    auto run = [&](const BIn<N> &d, int done, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
         const int nact = width(done);
         const bool live = lane < nact;
-        const int64_t t = te - 2 - done - lane;          // step index i = done + 1 + lane, t = te-1-i
-        const bool owned = done >= n_warm;               // wave-uniform
+        const int64_t tb = te - 2 - done;                // time of lane 0
+        const int64_t t = tb - lane;                     // step index i = done + 1 + lane, t = te-1-i
+        const bool owned = MODE == 1 || (MODE == 2 && done >= n_warm);   // wave-uniform
         int ws = (done + 1) % RB + lane;                 // (done+1) % RB is wave-uniform
         ws = ws >= RB ? ws - RB : ws;
         int rs = ws - L;
@@ -339,7 +365,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
         double e = -INFINITY;
 #pragma unroll
         for (int a = 0; a < N; a++) {
-            vb[a] = live ? DLv[a * RB + rs] : 0.0;
+            vb[a] = live ? DLv[a * (RB + 1) + rs] : 0.0;
             E[a] = (sbv + d.R[a]) + KC[KSC + a];         // sw_a
             e = fmax(e, scale_of(vb[a], E[a]));
         }
@@ -387,10 +413,11 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (live) {
+        const int wsl = live ? ws : RB;   // idle lanes write the spare slot behind the ring
 #pragma unroll
-            for (int a = 0; a < N; a++) DLv[a * RB + ws] = yn[a];
-            DLs[ws] = Mt;
+        for (int a = 0; a < N; a++) DLv[a * (RB + 1) + wsl] = yn[a];
+        DLs[wsl] = Mt;
+        if (MODE == 2 && live) {
             // boundary records for the certificate: values at the first L samples of the next
             // chain (warm-up) / of this chain (own sweep)
             double *rr = nullptr;
@@ -420,11 +447,11 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
 #pragma unroll
             for (int a = 0; a < N; a++) {
                 const double rv = own1 ? (d.fv[a] * wa[a]) * gg[1] : 0.0;
-                if (live) rhoc[(int64_t)a * T + t1] = rv;
+                *(live ? rhoc + (int64_t)a * T + t1 : trash + 64 * a + lane) = rv;
                 ra[a] += bulk ? rv : 0.0;
                 sx[a] += (own1 && t >= 0) ? wa[a] * gg[0] : 0.0;  // xi'_a(t+1): silent(t) -> (a,1)(t+1), :240
             }
-            if (c == 0 && t < L && live && t >= 0) {             // head of the recording: virtual onsets, pp
+            if (MODE == 2 && c == 0 && t < L && live && t >= 0) {   // head of the recording: virtual onsets, pp
                 double lg[N + 1];
 #pragma unroll
                 for (int a = 0; a < N; a++) lg[a] = yn[a];
@@ -455,7 +482,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
             const double sbv = DLs[slot], fr = FRc[tp];
 #pragma unroll
             for (int a = 0; a < N; a++) {
-                const double m = FVc[(int64_t)a * T + tp] * DLv[a * RB + slot];
+                const double m = FVc[(int64_t)a * T + tp] * DLv[a * (RB + 1) + slot];
                 const double s = ((fr + KC[KSC + a]) + Rc[(int64_t)a * T + tp]) + sbv;
                 if (on) zmax = fmax(zmax, scale_of(m, s));
             }
@@ -471,7 +498,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
             const double sbv = DLs[slot], fr = FRc[tp];
 #pragma unroll
             for (int a = 0; a < N; a++) {
-                mant[a] = FVc[(int64_t)a * T + tp] * DLv[a * RB + slot];
+                mant[a] = FVc[(int64_t)a * T + tp] * DLv[a * (RB + 1) + slot];
                 sc_[a] = mant[a] > 0.0 ? fmin((((fr + KC[KSC + a]) + Rc[(int64_t)a * T + tp]) + sbv) - zmax, 700.0) : -INFINITY;
             }
             fexp_n<N>(sc_);
@@ -494,23 +521,33 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
         __syncthreads();
     };
 
-    BIn<N> buf[D];
-    if (n_warm == 0) znorm();
     const int nsteps = n_total <= 0 ? 0 : 1 + (n_total - w0 + W - 1) / W;   // w0 first, then W each
+    const int kwarm = n_warm == 0 ? 0 : 1 + (n_warm - w0) / W;               // warm-up steps
+    const int rk = (L + W - 1) / W + 1;                                      // steps that touch a record window
+    // branch-free main loop over whole groups of D steps (see kw_fwd), remainder from the filled buffers
+    auto sweep = [&](int k0, int k1, auto mode_tag) {
+        BIn<N> buf[D];
 #pragma unroll
-    for (int i = 0; i < D; i++) load(buf[i], start(i));
-    for (int k0 = 0; k0 < nsteps; k0 += D) {
+        for (int i = 0; i < D; i++) load(buf[i], start(k0 + i));
+        int k = k0;
+        for (; k + D <= k1; k += D) {
 #pragma unroll
-        for (int i = 0; i < D; i++) {
-            const int k = k0 + i;
-            if (k < nsteps) {
-                const int done = start(k);
-                run(buf[i], done);
-                load(buf[i], start(k + D));
-                if (done + width(done) == n_warm) znorm();
+            for (int i = 0; i < D; i++) {
+                run(buf[i], start(k + i), mode_tag);
+                load(buf[i], start(k + i + D));
             }
         }
-    }
+#pragma unroll
+        for (int i = 0; i < D; i++)
+            if (k + i < k1) run(buf[i], start(k + i), mode_tag);
+    };
+    const int kw1 = kwarm - rk > 0 ? kwarm - rk : 0;
+    if (kw1 > 0) sweep(0, kw1, std::integral_constant<int, 0>());
+    if (kwarm > kw1) sweep(kw1, kwarm, std::integral_constant<int, 2>());
+    znorm();
+    const int ko1 = nsteps - rk > kwarm ? nsteps - rk : kwarm;
+    if (ko1 > kwarm) sweep(kwarm, ko1, std::integral_constant<int, 1>());
+    if (nsteps > ko1) sweep(ko1, nsteps, std::integral_constant<int, 2>());
     // per-chain partial sums -> partS[cg][2N+3] = sx | ra | s_all s_m s_y2
     double *ps = partS + (int64_t)cg * (2 * N + 3);
 #pragma unroll
@@ -658,14 +695,18 @@ __global__ __launch_bounds__(256) void kw_gsum_generic(WaveGeom g, const double 
     if (p < NL) { out[p] = s1; out[NL + p] = s2; }
 }
 
-// Matrix-core statistics for few rings (N <= 8): see the derivation at k_gsum_mx (ring_estep.hip).
-// The 16 columns of the B operand hold NS = 16/NP delayed copies of the NP rings, so one
-// v_mfma_f64_16x16x4_f64 accumulates LPT = 16 NS consecutive lags of every ring with no padded
-// column.  Natural layout: a "column" is a block of kGxBv consecutive samples; a workgroup sweeps 64
-// columns as 8 groups of 8, wave w takes columns 2w, 2w+1 of a group; tiles of TR rows staged
-// through LDS with all global loads contiguous in time.
+// Matrix-core statistics for few rings (N <= 8): the spike-triggered sums are a matrix product over
+// time, C[16 lags x 16 columns] += A[16 x 4 samples] B[4 x 16] per v_mfma_f64_16x16x4_f64 with A a
+// Toeplitz window of y and B the posteriors.  The 16 B-columns hold NS = 16/NP delayed copies of the NP
+// rings (copy s delayed by 16 s samples: B[kk][a + NP s] = rho_a(tau + kk - 16 s)), so one MFMA
+// accumulates LPT = 16 NS consecutive lags of every ring with no padded column (N = 4, L = 59: all 59
+// lags of all 4 rings in ONE accumulator tile).  Natural layout: a "column" is a block of kGxBv
+// consecutive samples (rho outside the column staged as zeros, y read on into the next column); a
+// workgroup sweeps kGxSubs groups of 8 columns, wave w takes columns 2w, 2w+1 of a group.  Tiles of TR
+// rows go global -> registers -> LDS; the next tile's global loads are in flight during the MFMAs.
+// LDS rows of rho are padded by one row per 16 (the 4 delayed copies would otherwise hit one bank).
 typedef double wg_d4 __attribute__((ext_vector_type(4)));
-constexpr int kGxTR = 64, kGxBv = 256;
+constexpr int kGxTR = 64, kGxBv = 256, kGxSubs = 2;
 
 template <int N, int NT>
 __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__restrict__ y,
@@ -675,11 +716,14 @@ __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__re
     constexpr int NP = N <= 1 ? 1 : (N <= 2 ? 2 : (N <= 4 ? 4 : 8));
     constexpr int NS = 16 / NP, LPT = 16 * NS, HS = 16 * (NS - 1);
     constexpr int TR = kGxTR, CW = 8, RR = TR + HS, Bv = kGxBv;
+    constexpr int RRP = RR + RR / 16 + 1;          // padded rho rows per column
+    constexpr int YR = TR + 19 + LPT * (NT - 1);   // staged y rows per column (odd)
+    constexpr int RS = RRP * NP + 2;               // rho column stride
+    constexpr int TPS = (Bv + HS + TR - 1) / TR;   // tiles per column group
+    constexpr int NRH = (NP * RR * CW + 255) / 256, NYM = (CW * (YR - 1) + 255) / 256;
     extern __shared__ double lds[];
     const int L = g.L, ch = blockIdx.y;
     const int64_t T = g.T;
-    constexpr int YR = TR + 19 + LPT * (NT - 1);   // staged y rows per column (odd)
-    constexpr int RS = RR * NP + 2;                // rho column stride
     double *lr = lds;                              // [CW][RS]
     double *ly = lds + CW * RS;                    // [CW][YR]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -688,58 +732,62 @@ __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__re
     wg_d4 c1[NT], c2[NT];
 #pragma unroll
     for (int q = 0; q < NT; q++) { c1[q] = wg_d4{0.0, 0.0, 0.0, 0.0}; c2[q] = wg_d4{0.0, 0.0, 0.0, 0.0}; }
-    for (int sub = 0; sub < 64 / CW; sub++) {
-        const int64_t col0 = (int64_t)blockIdx.x * 64 + sub * CW;
-        if (col0 * Bv >= T) break;
-        for (int s0 = 0; s0 < Bv + HS; s0 += TR) {
-            constexpr int NRH = (NP * RR * CW + 255) / 256, NYM = (CW * (YR - 1) + 255) / 256;
-            double tr_[NRH], ty_[NYM];
+    int ntiles = 0;
+    for (int sub = 0; sub < kGxSubs; sub++)
+        if (((int64_t)blockIdx.x * kGxSubs + sub) * CW * Bv < T) ntiles += TPS;
+    double tr_[NRH], ty_[NYM];
+    auto load_regs = [&](int ti) {   // ring index fastest: conflict-free LDS stores, 128-byte global segments
+        const int sub = ti / TPS, s0 = (ti % TPS) * TR;
+        const int64_t col0 = ((int64_t)blockIdx.x * kGxSubs + sub) * CW;
 #pragma unroll
-            for (int k = 0; k < NRH; k++) {   // rho rows s0-HS .. s0+TR-1 of every column, time fastest
-                const int i = tid + k * 256;
-                const int u = i % RR, rest = i / RR, cc = rest % CW, a = rest / CW;
-                const int row = s0 - HS + u;
-                const int64_t t = (col0 + cc) * Bv + row;
-                const bool ok = i < NP * RR * CW && a < N && row >= 0 && row < Bv && t < T;
-                const double v = rc[ok ? (int64_t)a * T + t : 0];
-                tr_[k] = ok ? v : 0.0;
-            }
+        for (int k = 0; k < NRH; k++) {
+            const int i = tid + k * 256;
+            const int a = i % NP, rest = i / NP, u = rest % RR, cc = rest / RR;
+            const int row = s0 - HS + u;
+            const int64_t t = (col0 + cc) * Bv + row;
+            const bool ok = i < NP * RR * CW && a < N && row >= 0 && row < Bv && t < T;
+            const double v = rc[ok ? (int64_t)a * T + t : 0];
+            tr_[k] = ok ? v : 0.0;
+        }
 #pragma unroll
-            for (int k = 0; k < NYM; k++) {   // y rows s0 .. s0+YR-2
-                const int i = tid + k * 256;
-                const int rr = i % (YR - 1), cc = i / (YR - 1);
-                const int64_t t = (col0 + cc) * Bv + s0 + rr;
-                const bool ok = i < CW * (YR - 1) && t < T;
-                const double v = yc[ok ? t : 0];
-                ty_[k] = ok ? v : 0.0;
-            }
-            __syncthreads();  // the previous tile has been consumed
+        for (int k = 0; k < NYM; k++) {
+            const int i = tid + k * 256;
+            const int rr = i % (YR - 1), cc = i / (YR - 1);
+            const int64_t t = (col0 + cc) * Bv + s0 + rr;
+            const bool ok = i < CW * (YR - 1) && t < T;
+            const double v = yc[ok ? t : 0];
+            ty_[k] = ok ? v : 0.0;
+        }
+    };
+    if (ntiles > 0) load_regs(0);
+    for (int ti = 0; ti < ntiles; ti++) {
+        __syncthreads();  // the previous tile has been consumed
 #pragma unroll
-            for (int k = 0; k < NRH; k++) {
-                const int i = tid + k * 256;
-                const int u = i % RR, rest = i / RR, cc = rest % CW, a = rest / CW;
-                if (i < NP * RR * CW) lr[cc * RS + u * NP + a] = tr_[k];
-            }
+        for (int k = 0; k < NRH; k++) {
+            const int i = tid + k * 256;
+            const int a = i % NP, rest = i / NP, u = rest % RR, cc = rest / RR;
+            if (i < NP * RR * CW) lr[cc * RS + (u + u / 16) * NP + a] = tr_[k];
+        }
 #pragma unroll
-            for (int k = 0; k < NYM; k++) {
-                const int i = tid + k * 256;
-                if (i < CW * (YR - 1)) ly[(i / (YR - 1)) * YR + i % (YR - 1)] = ty_[k];
-            }
-            __syncthreads();
+        for (int k = 0; k < NYM; k++) {
+            const int i = tid + k * 256;
+            if (i < CW * (YR - 1)) ly[(i / (YR - 1)) * YR + i % (YR - 1)] = ty_[k];
+        }
+        __syncthreads();
+        if (ti + 1 < ntiles) load_regs(ti + 1);   // in flight during the MFMAs
 #pragma unroll
-            for (int h = 0; h < CW / 4; h++) {
-                const int cc = wv * (CW / 4) + h;
-                const double *lrc = lr + cc * RS + (lk - 16 * lsft + HS) * NP + la;
-                const double *lyc = ly + cc * YR + lk + lj;
+        for (int h = 0; h < CW / 4; h++) {
+            const int cc = wv * (CW / 4) + h;
+            const double *lyc = ly + cc * YR + lk + lj;
 #pragma unroll 4
-                for (int ts = 0; ts < TR / 4; ts++) {
-                    const double b = lrc[ts * 4 * NP];
+            for (int ts = 0; ts < TR / 4; ts++) {
+                const int u = lk - 16 * lsft + HS + 4 * ts;          // staged row of rho_a(tau + kk - 16 s)
+                const double b = lr[cc * RS + (u + u / 16) * NP + la];
 #pragma unroll
-                    for (int q = 0; q < NT; q++) {
-                        const double a = lyc[ts * 4 + q * LPT];
-                        c1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1[q], 0, 0, 0);
-                        c2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a * a, b, c2[q], 0, 0, 0);
-                    }
+                for (int q = 0; q < NT; q++) {
+                    const double a = lyc[ts * 4 + q * LPT];
+                    c1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1[q], 0, 0, 0);
+                    c2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a * a, b, c2[q], 0, 0, 0);
                 }
             }
         }
@@ -888,18 +936,18 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
     int rowsG = 0;
     int rc = dispatch_N(N, [&](auto n) {
         constexpr int NN = decltype(n)::value;
-        const size_t ldsf = ((size_t)2 * NN * g.RB + 5 + 3 * NN + NN * NN) * sizeof(double);
-        const size_t ldsb = ((size_t)(NN + 1) * g.RB + 4 + 3 * NN + NN * NN) * sizeof(double);
+        const size_t ldsf = ((size_t)2 * NN * (g.RB + 1) + 5 + 3 * NN + NN * NN) * sizeof(double);
+        const size_t ldsb = ((size_t)(NN + 1) * (g.RB + 1) + 4 + 3 * NN + NN * NN) * sizeof(double);
         auto kf = r->uniform_cx ? kw_fwd<NN, true> : kw_fwd<NN, false>;
         auto kb = r->uniform_cx ? kw_bwd<NN, true> : kw_bwd<NN, false>;
         int rc2;
         if ((rc2 = wave_lds_attr2(kf, ldsf)) || (rc2 = wave_lds_attr2(kb, ldsb))) return rc2;
         { WPROF(r, "kw_fwd", st);
           hipLaunchKernelGGL(kf, dim3(nchT), dim3(64), ldsf, st, g, r->d_cst, d_y, r->Rf, r->virt, r->FA0,
-                             r->FV, r->FREF, r->fpre); }
+                             r->FV, r->FREF, r->fpre, r->trash); }
         { WPROF(r, "kw_bwd", st);
           hipLaunchKernelGGL(kb, dim3(nchT), dim3(64), ldsb, st, g, r->d_cst, d_y, r->Rf, r->FA0, r->FV,
-                             r->FREF, r->fpre, r->rho, r->partS, r->Zc, r->bpre, r->bown, r->yhead); }
+                             r->FREF, r->fpre, r->rho, r->partS, r->Zc, r->bpre, r->bown, r->yhead, r->trash); }
         HS_HIP(hipGetLastError());
         // certificate + edge terms beside the statistics kernel
         HS_HIP(hipEventRecord(r->ev_a, st));
@@ -918,8 +966,9 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
         const int ntx = (L + LPTx - 1) / LPTx;
         const bool generic = getenv("HMMSORT_GSUM_GENERIC") != nullptr;
         if (!generic && NN <= 8 && ntx <= 4) {
-            rowsG = (int)((g.T + 64 * (int64_t)kGxBv - 1) / (64 * (int64_t)kGxBv));
-            const size_t l1 = ((size_t)8 * ((kGxTR + HSx) * NPx + 2) + (size_t)8 * (kGxTR + 19 + LPTx * (ntx - 1))) * 8;
+            rowsG = (int)((g.T + kGxSubs * 8 * (int64_t)kGxBv - 1) / (kGxSubs * 8 * (int64_t)kGxBv));
+            constexpr int RRx = kGxTR + HSx, RRPx = RRx + RRx / 16 + 1;
+            const size_t l1 = ((size_t)8 * (RRPx * NPx + 2) + (size_t)8 * (kGxTR + 19 + LPTx * (ntx - 1))) * 8;
             const size_t l2 = (size_t)4 * ntx * 2 * 4 * 64 * 8;
             const size_t lds = l1 > l2 ? l1 : l2;
             constexpr int NM = NN <= 8 ? NN : 8;

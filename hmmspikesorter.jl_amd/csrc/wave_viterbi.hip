@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64, wave_occ<N>()) void kw_vit(WaveGeom g, const Wa
                                                             const double *__restrict__ ysum,
                                                             uint32_t *__restrict__ psi, double *__restrict__ vpre,
                                                             double *__restrict__ vend,
-                                                            const int32_t *__restrict__ vfail, int redo)
+                                                            const int32_t *__restrict__ vfail, uint32_t *__restrict__ trash,
+                                                            int redo)
 {
     constexpr int EB = wpsi_bits_c(N), EPW = wpsi_epw_c(N), PW = wpsi_words_c(N), D = wave_depth<N>();
     // Model constants live in LDS next to the delay line: they are wave-uniform and many; as
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(64, wave_occ<N>()) void kw_vit(WaveGeom g, const Wa
     const int64_t planePsi = (int64_t)g.C * T;
     const double thr = wave_thr(g, cst[ch], ysum, ch);
 
-    for (int i = lane; i < N * RB; i += 64) DL[i] = -INFINITY;
+    for (int i = lane; i < N * (RB + 1); i += 64) DL[i] = -INFINITY;
     {
         const WaveConst &Kg = cst[ch];
         if (lane == 0) { KC[0] = Kg.c00; KC[1] = Kg.mean0; KC[2] = Kg.den; }
@@ -109,16 +110,16 @@ __global__ __launch_bounds__(64, wave_occ<N>()) void kw_vit(WaveGeom g, const Wa
         D0 = vend[(cg - 1) * SR];
         for (int i = lane; i < N * L; i += 64) {
             const int a = i / L, j = i % L + 1;
-            DL[a * RB + (L + 1 - j)] = vend[(cg - 1) * SR + 1 + i];
+            DL[a * (RB + 1) + (L + 1 - j)] = vend[(cg - 1) * SR + 1 + i];
         }
     } else if (c == 0) {   // the reference's first column (viterbi.jl:55-63): emission only, T1[1,1] = 0
         tinit = 0;
         D0 = -cst[ch].A;
         for (int i = lane; i < N * L; i += 64) {
             const int a = i / L, j = i % L + 1;  // virtual onset -j -> slot L - j
-            DL[a * RB + (L - j)] = virt[((int64_t)ch * N + a) * (L + 1) + j];
+            DL[a * (RB + 1) + (L - j)] = virt[((int64_t)ch * N + a) * (L + 1) + j];
         }
-        if (lane < N) DL[lane * RB + L] = Rc[(int64_t)lane * T];
+        if (lane < N) DL[lane * (RB + 1) + L] = Rc[(int64_t)lane * T];
     } else {               // warm-up start: silent, rings empty
         tinit = tc - g.Hw;
         D0 = 0.0;
@@ -137,14 +138,19 @@ __global__ __launch_bounds__(64, wave_occ<N>()) void kw_vit(WaveGeom g, const Wa
         for (int a = 0; a < N; a++) d.R[a] = (Rc + (int64_t)a * T + tb)[li];
     };
     int rs = (1 + lane) % RB, ws = (L + 1 + lane) % RB;
-    auto run = [&](const WIn<N> &d, int off) {
+    // STORE = 0: warm-up super-step (no global stores at all); 1: owned super-step (psi stored by every
+    // lane, idle lanes of the last partial step into a trash line).  Straight-line global accesses only:
+    // with stores under divergent branches hipcc drains vmcnt to 0 every super-step, which serialises the
+    // input pipeline on the HBM latency.
+    auto run = [&](const WIn<N> &d, int off, auto store_tag) {
+        constexpr int STORE = decltype(store_tag)::value;
         const int nact = n_total - off < W ? n_total - off : W;
         const bool live = lane < nact;
         const int64_t tb = tinit + 1 + off;
         double X[N];
 #pragma unroll
         for (int a = 0; a < N; a++) {
-            const double v = DL[a * RB + rs];
+            const double v = DL[a * (RB + 1) + rs];
             X[a] = live ? v : -INFINITY;
         }
         // ring exits into the silent state: best and runner-up among the rings (first maximum wins)
@@ -190,6 +196,7 @@ __global__ __launch_bounds__(64, wave_occ<N>()) void kw_vit(WaveGeom g, const Wa
                 m1 = g1 ? v : m1;
             }
         }
+        const int wsl = live ? ws : RB;   // idle lanes write a spare slot behind the ring (branch-free stores)
 #pragma unroll
         for (int a = 0; a < N; a++) {
             double r1 = -INFINITY, r2 = -INFINITY;
@@ -216,14 +223,17 @@ __global__ __launch_bounds__(64, wave_occ<N>()) void kw_vit(WaveGeom g, const Wa
             const double u = ring ? r1 : v0;
             const double gap = ring ? r1 - fmax(r2, v0) : v0 - r1;
             const uint32_t fl = gap < thr ? 1u : 0u;
-            if (live) DL[a * RB + ws] = u + d.R[a];
+            DL[a * (RB + 1) + wsl] = u + d.R[a];
             const uint32_t ent = (ring ? (uint32_t)rarg : 0u) | (fl << (EB - 1));
             pw[(a + 1) / EPW] |= ent << (((a + 1) % EPW) * EB);
             if (!UC) __builtin_amdgcn_sched_barrier(0);   // keep the junctions sequential: N^2 live candidates otherwise
         }
-        if (live && tb + lane >= tc) {
+        if (STORE) {
 #pragma unroll
-            for (int w = 0; w < PW; w++) (psic + w * planePsi + tb)[lane] = pw[w];
+            for (int w = 0; w < PW; w++) {
+                uint32_t *dst = live ? psic + w * planePsi + tb + lane : trash + lane;
+                *dst = pw[w];
+            }
         }
         D0 = wave_bcast(Dn, 63);  // idle lanes carry the identity, so lane 63 holds the last live value
         rs += W; rs = rs >= RB ? rs - RB : rs;
@@ -235,27 +245,36 @@ __global__ __launch_bounds__(64, wave_occ<N>()) void kw_vit(WaveGeom g, const Wa
         for (int i = lane; i < N * L; i += 64) {
             const int a = i / L, j = i % L + 1;
             const int slot = (int)((tref - j - tinit + L) % RB);
-            rec[1 + i] = DL[a * RB + slot];
+            rec[1 + i] = DL[a * (RB + 1) + slot];
         }
         __syncthreads();
     };
-
     // D super-steps of input in flight; the ring of buffers is indexed statically
-    WIn<N> buf[D];
-    const int n_warm = (redo || c == 0) ? -1 : g.Hw - 1;
+    // The main loop is branch-free (whole groups of D super-steps, loads clamped past the end), so that
+    // hipcc can count vmcnt across the back edge; the last < D super-steps run from the buffers the main
+    // loop has already filled.
+    auto sweep = [&](int from, int to, auto store_tag) {
+        WIn<N> buf[D];
 #pragma unroll
-    for (int i = 0; i < D; i++) load(buf[i], i * W);
-    for (int off = 0; off < n_total; off += D * W) {
+        for (int i = 0; i < D; i++) load(buf[i], from + i * W);
+        int off = from;
+        for (; off + D * W <= to; off += D * W) {
 #pragma unroll
-        for (int i = 0; i < D; i++) {
-            const int o = off + i * W;
-            if (o < n_total) {
-                run(buf[i], o);
-                load(buf[i], o + D * W);
-                if (o + W == n_warm) dump(vpre + cg * SR, tc);
+            for (int i = 0; i < D; i++) {
+                run(buf[i], off + i * W, store_tag);
+                load(buf[i], off + (i + D) * W);
             }
         }
+#pragma unroll
+        for (int i = 0; i < D; i++)
+            if (off + i * W < to) run(buf[i], off + i * W, store_tag);
+    };
+    const int n_warm = (redo || c == 0) ? 0 : g.Hw - 1;
+    if (n_warm > 0) {
+        sweep(0, n_warm, std::integral_constant<int, 0>());
+        dump(vpre + cg * SR, tc);
     }
+    sweep(n_warm, n_total, std::integral_constant<int, 1>());
     dump(vend + cg * SR, tend);
     if (redo) {  // the hand-off was exact by construction
         for (int i = lane; i < SR; i += 64) vpre[cg * SR + i] = vend[(cg - 1) * SR + i];
@@ -597,13 +616,13 @@ int wave_viterbi_sweep(WaveDev *r, const double *d_y, hipStream_t st)
     const int nchT = g.C * g.nch;
     return dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
-        const size_t lds = ((size_t)N * g.RB + 3 + 2 * N + N * N) * sizeof(double);
+        const size_t lds = ((size_t)N * (g.RB + 1) + 3 + 2 * N + N * N) * sizeof(double);
         auto kern = r->uniform_cx ? kw_vit<N, true> : kw_vit<N, false>;
         int rc = wave_lds_attr(kern, lds);
         if (rc) return rc;
         { WPROF(r, "kw_vit", st);
           hipLaunchKernelGGL(kern, dim3(nchT), dim3(64), lds, st, g, r->d_cst, d_y, r->Rf, r->virt, r->ysum,
-                             r->psi, r->vpre, r->vend, r->vfail, 0); }
+                             r->psi, r->vpre, r->vend, r->vfail, (uint32_t *)r->trash, 0); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
     });
@@ -616,14 +635,14 @@ int wave_viterbi_post(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll,
     const int nchT = g.C * g.nch;
     int rc = dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
-        const size_t lds = ((size_t)N * g.RB + 3 + 2 * N + N * N) * sizeof(double);
+        const size_t lds = ((size_t)N * (g.RB + 1) + 3 + 2 * N + N * N) * sizeof(double);
         auto kern = r->uniform_cx ? kw_vit<N, true> : kw_vit<N, false>;
         for (int round = 0; round < kVitRounds && g.nch > 1; round++) {
             { WPROF(r, "kw_vit_check", st);
               hipLaunchKernelGGL(kw_vit_check, dim3(nchT), dim3(64), 0, st, g, r->vpre, r->vend, r->vfail, r->diag, 0); }
             { WPROF(r, "kw_vit_redo", st);
               hipLaunchKernelGGL(kern, dim3(nchT), dim3(64), lds, st, g, r->d_cst, d_y, r->Rf, r->virt,
-                                 r->ysum, r->psi, r->vpre, r->vend, r->vfail, 1); }
+                                 r->ysum, r->psi, r->vpre, r->vend, r->vfail, (uint32_t *)r->trash, 1); }
         }
         { WPROF(r, "kw_vit_check", st);
           hipLaunchKernelGGL(kw_vit_check, dim3(nchT), dim3(64), 0, st, g, r->vpre, r->vend, r->vfail, r->diag, 1); }
