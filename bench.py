@@ -31,38 +31,63 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s measured streaming
 
 
-def algorithmic_bytes(kernel, S, T):
-    """B(S) = 18*S + 28 bytes/sample for the combined metric, split by
-    sweep: forward reads y (8) and writes alpha (8S); backward re-reads y and alpha (8S+8);
-    Viterbi reads y (8), writes psi as Int16 per state (2S); backtrace reads >= 2 and writes x (2)."""
+def contract_bytes(S, T):
+    """SURVEY.md section 8(d) contract figure: B(S) = 18*S + 28 bytes/sample for the combined metric (what a
+    trellis-materialising implementation moves: forward writes alpha 8S, backward re-reads it, Viterbi
+    writes psi 2S, ...).  The engines here never write the trellis, so this is NOT what they move; it is
+    quoted as `frac_contract` only."""
+    return (18 * S + 28) * T
+
+
+def engine_bytes(kernel, N, T, info):
+    """HBM bytes one launch of `kernel` has to move BY DESIGN (wave engine, natural-layout arrays; the
+    delay lines live in LDS).  Used for the whole-step figure and as the fall-back when no rocprofv3
+    counter summary of these very kernel sources is committed."""
+    B, H = max(1, info["block"]), info["halo"]
+    warm = 1.0 + H / B                       # every chain re-reads its warm-up
+    pw = {True: 1, False: 2}[N <= 4] if N <= 8 else 4
     per_sample = {
-        "k_vfb_chain": (2 * S + 8) + 2 * (8 * S + 8),  # Viterbi + forward + backward sweeps, one launch
-        "k_fb_chain": 2 * (8 * S + 8),      # forward and backward sweeps in one launch
-        "k_fwd_chain": 8 * S + 8,
-        "k_bwd_chain": 8 * S + 8,
-        "k_vit_chain": 2 * S + 8,
-        "k_vit_backtrace": 4,
-    }.get(kernel, 8)
-    return per_sample * T
+        "kw_prepass": 8 + 8 * N,                         # y in, N ring-score planes out
+        "kw_vit": (8 + 8 * N) * warm + 4 * pw,           # y + ring scores in, packed back-pointers out
+        "kw_fwd": (8 + 8 * N) * warm + 8 * (N + 2),      # ... la0, fref, N onset masses out
+        "kw_bwd": (8 + 8 * N) * warm + 8 * (N + 2) + 8 * N,   # y, ring scores, forward outputs in; rho out
+        "kw_gsum": 8 + 8 * N,                            # y, rho in
+        "kw_backtrace": 4 * pw * 1.25 + 2,               # psi (with walk-in) in, x out
+        "kw_ll_partial": 8 + 2,
+        "kw_fb_check": 0.1, "kw_edges": 0.0,
+    }.get(kernel)
+    return None if per_sample is None else per_sample * T
 
 
-def measured_traffic(kernel, T, block, halo):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same
-    command (profiles/<tag>_summary.json, written by profiles/summarize.py from separate
-    --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction).  None when no
-    summary matches the workload."""
+def kernel_sources_hash():
     import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "hmmspikesorter.jl_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")) +
+                    glob.glob(os.path.join(src, "*.cpp"))):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(T, block):
+    """Per-kernel HBM bytes per launch from a committed rocprofv3 PMC summary (profiles/<tag>_summary.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 x2 read correction) -- but only
+    of a summary taken with EXACTLY the kernel sources this process runs (_meta.kernel_sources) on the
+    same workload; otherwise None, and the line says so."""
+    import glob
+    want = kernel_sources_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         meta = d.get("_meta", {})
-        if meta.get("samples") == T and meta.get("block") == block and meta.get("halo") == halo \
-                and kernel in d:
-            best = (d[kernel]["hbm_read_bytes"] + d[kernel]["hbm_write_bytes"], os.path.basename(path))
-    return best
+        if meta.get("kernel_sources") == want and meta.get("samples") == T and meta.get("block") == block:
+            return {k: v["hbm_read_bytes"] + v["hbm_write_bytes"] for k, v in d.items() if k != "_meta"}, \
+                os.path.basename(path)
+    return None, None
 
 
 def cpu_baseline(H, N, K, temps, pp, sigma):
@@ -235,19 +260,39 @@ def main():
     diag = plan.diagnostics(stream)
     plan.estep(dy, stats, stream)
     dE = plan.diagnostics(stream)
-    diag = diag[:3] + dE[3:7]
+    diag = diag[:3] + dE[3:7] + diag[7:8]
 
     # ---- per-kernel timing (HIP events on the launch stream; separate, untimed pass) ----
+    # decode and E-step as two calls here: in the timed step their kernels overlap on two streams, which
+    # stretches every kernel's event-to-event time; run one after the other the durations are each kernel's own
     plan.profile(True)
     for _ in range(max(1, min(args.steps, 5))):
-        step()
+        plan.bind(dy, stream)
+        plan.viterbi(dy, dx, dll, stream)
+        plan.estep(dy, stats, stream)
+        plan.mstep(stats, out, stream)
+        plan.unbind()
     prof = plan.profile_read(stream)
     plan.profile(False)
     ksum = {k: v[0] / v[1] for k, v in prof.items()}           # average ms per launch
+    nprof = max(1, min(args.steps, 5))
+    per_step_ms = {k: v[0] / nprof for k, v in prof.items()}   # ms per step (a kernel may launch more than once)
     dom = max(ksum, key=ksum.get)
-    achieved = algorithmic_bytes(dom, S, T) / (ksum[dom] * 1e-3) / 1e9
-    step_ms_kernels = sum(v[0] for v in prof.values()) / max(1, min(args.steps, 5))
-    traffic = measured_traffic(dom, T, info["block"], info["halo"])
+    step_ms_kernels = sum(per_step_ms.values())
+    counters, counters_src = measured_traffic(T, info["block"]) if info["engine"] == H.ENGINE_WAVE else (None, None)
+    model = {k: engine_bytes(k, N, T, info) for k in ksum}
+    dom_counter = counters.get(dom) if counters else None
+    dom_bytes = dom_counter if dom_counter is not None else model.get(dom)
+    bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
+    achieved = dom_bytes / (ksum[dom] * 1e-3) / 1e9 if dom_bytes else None
+    if dom == "kw_gsum":
+        # the statistics kernel is a Toeplitz matrix product on the fp64 matrix cores: G1/G2[lag][ring] over
+        # all onsets = 2 (G1,G2) x 2 flop x N L T useful flops; fp64 MFMA peak = the fp64 vector rate,
+        # 78.6 TFLOP/s (MI355X_MICROARCH.md: FP32 vector 157.3 TF, fp64 at half rate)
+        bound, peak, unit = "mfma", 78.6, "TFLOP/s"
+        achieved = 4.0 * N * (K - 1) * T / (ksum[dom] * 1e-3) / 1e12
+    step_bytes_model = sum(v for v in model.values() if v)
+    step_bytes_counters = (sum(counters.get(k, 0.0) * prof[k][1] / nprof for k in ksum) if counters else None)
 
     # split timings (untimed region): Viterbi only / E-step only
     def timed(fn, n=3):
@@ -295,32 +340,50 @@ def main():
         # rebuilt by the host, which this fixed-shape loop does not do
         em_ms, em_sigma = None, "stopped: %s" % exc
 
-    # ---- several channels per GPU, one plan + one stream each (the serving shape of a multi-
-    # channel probe; untimed extra, reported in detail only) ----
-    def multi_channel(nchan):
-        plans, streams, bufs = [], [], []
+    # ---- several channels per GPU through ONE batched plan (hmmsort_plan_create_batched: chains =
+    # channels x chains per channel, per-channel models; the shape of BASELINE config 4's per-GPU share;
+    # untimed extra, reported in detail only) ----
+    def multi_channel(nchan, Nc=N, Kc=K, Tc=T, steps=3):
+        if (Nc, Kc) == (N, K):
+            tm, ppc, smc = temps, pp, sm
+        else:
+            tm = np.asfortranarray(np.stack([H.create_spike_template(Kc, *amps_for(Nc)[i]) for i in range(Nc)], 1))
+            ppc = [[0.003, 0.001, 0.002, 0.0015][i % 4] * (60.0 / Kc) for i in range(Nc)]
+            smc = H.StateMatrix.create(Nc, Kc, np.log(ppc), False)
+        pl = H.Plan.batched(Tc, [smc] * nchan, [tm] * nchan, [sigma] * nchan)
+        yy = torch.empty((nchan, Tc), dtype=torch.float64, device=dev)
         for ch in range(nchan):
-            pl = H.Plan(T, sm, temps, sigma)
-            stc = torch.cuda.Stream()
-            yy = dy if ch == 0 else torch.from_numpy(H.create_signal(T, sigma, pp, temps, seed=seed + 100 + ch)).to(dev)
-            bufs.append((yy, torch.zeros(T, dtype=torch.int16, device=dev),
-                         torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros_like(stats),
-                         torch.zeros_like(out)))
-            plans.append(pl); streams.append(stc)
+            yy[ch] = torch.from_numpy(H.create_signal(Tc, sigma, ppc, tm, seed=seed + 100 + ch)).to(dev)
+        xx = torch.zeros((nchan, Tc), dtype=torch.int16, device=dev)
+        ll_ = torch.zeros(nchan, dtype=torch.float64, device=dev)
+        ss = torch.zeros((nchan, pl.stats_len()), dtype=torch.float64, device=dev)
+        oo = torch.zeros((nchan, pl.mstep_len()), dtype=torch.float64, device=dev)
         def go():
-            for pl, stc, (yy, xx, ll_, ss, oo) in zip(plans, streams, bufs):
-                h = stc.cuda_stream
-                pl.bind(yy, h); pl.decode_estep(yy, xx, ll_, ss, h); pl.mstep(ss, oo, h); pl.unbind()
+            pl.bind(yy, stream); pl.decode_estep(yy, xx, ll_, ss, stream); pl.mstep(ss, oo, stream); pl.unbind()
         go(); torch.cuda.synchronize()
         t = time.perf_counter()
-        for _ in range(3):
+        for _ in range(steps):
             go()
         torch.cuda.synchronize()
-        per = (time.perf_counter() - t) / 3
-        for pl in plans:
-            pl.close()
-        return nchan * T / per / 1e6
-    mc = multi_channel(args.channels) if (args.channels > 1 and not args.time_sharded and not args.quick) else None
+        per = (time.perf_counter() - t) / steps
+        dg = pl.diagnostics(stream)
+        io = pl.info()
+        pl.close()
+        return {"channels_per_gpu": nchan, "model": "N=%d K=%d" % (Nc, Kc), "samples_per_channel": Tc,
+                "Msamples_s": nchan * Tc / per / 1e6, "ms_per_step": per * 1e3, "block": io["block"],
+                "chains": io["nchains"], "boundary_check_fails": [dg[0], dg[3], dg[5]], "near_ties_on_path": dg[7],
+                "workspace_GB": io["workspace_bytes"] / 1e9}
+
+    def amps_for(Nc):
+        base_ = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)]
+        return [(base_[i % 4][0] * (1 + 0.13 * (i // 4)), base_[i % 4][1] + 0.03 * (i // 4), base_[i % 4][2])
+                for i in range(Nc)]
+    extras = args.channels > 1 and not args.time_sharded and not args.quick and world == 1
+    mc = multi_channel(args.channels) if extras else None
+    # BASELINE config 4 (per-GPU share: 8 channels x 10 M, N=8, K=128) and config 5 (N=16, K=256; one
+    # 40 M-sample channel here, the 100 M-sample run is tests/test_gpu_configs.py) -- untimed extras
+    cfg4 = multi_channel(8, 8, 128, 10_000_000, steps=2) if (extras and (N, K) == (4, 60)) else None
+    cfg5 = multi_channel(1, 16, 256, 40_000_000, steps=2) if (extras and (N, K) == (4, 60)) else None
 
     # ---- overlap-resolving decode: the reference's own Viterbi-test model,
     # test/runtests.jl:17-34 -- 2 templates, K=60, allow_overlaps=true, 3600 states -- through the
@@ -349,8 +412,8 @@ def main():
                 "boundary_check_fails": d[0], "max_boundary_spread": d[2], "near_tie_blocks": d[7]}
     ov = overlap_decode() if (rank == 0 and world == 1 and not args.quick) else None
 
+    ms = dt / args.steps * 1e3
     if rank == 0:
-        ms = dt / args.steps * 1e3
         res = {
             "metric": "Msamples/sec (Viterbi + forward-backward), K=%d L=%d HMM" % (N, K),
             "value": (T_total if args.time_sharded else world * T) / (dt / args.steps) / 1e6,
@@ -367,28 +430,40 @@ def main():
                        "engine": engine_name, "block": info["block"], "halo": info["halo"],
                        "chains": info["nchains"], "seed": 1234, "pooled_allreduce": bool(args.pooled),
                        "time_sharded": bool(args.time_sharded)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic[0] if traffic else None,
-                         "traffic_source": traffic[1] if traffic else None,
-                         "traffic_GBps": (traffic[0] / (ksum[dom] * 1e-3) / 1e9) if traffic else None,
+            "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": peak,
+                         "unit": unit, "frac": (achieved / peak) if achieved else None,
+                         "traffic": dom_counter,
+                         "traffic_source": counters_src if dom_counter is not None else
+                         "none committed for these kernel sources: achieved/frac use the engine's design bytes",
+                         "traffic_model": model.get(dom),
                          "avg_launch_ms": ksum[dom],
-                         "note": "achieved = SURVEY 8(d) algorithmic bytes of the sweep this kernel "
-                                 "implements (a trellis-materialising sweep) / HIP-event launch time; "
-                                 "the ring engine never writes the trellis (junction-only recursion), "
-                                 "so frac > 1; traffic = HBM bytes per launch actually moved "
-                                 "(rocprofv3 PMC), traffic_GBps = that over the same launch time"},
+                         "frac_contract": contract_bytes(S, T) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "step": {"ms": ms, "bytes_model": step_bytes_model, "bytes_counters": step_bytes_counters,
+                                  "frac": (step_bytes_counters or step_bytes_model) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "note": "frac = HBM bytes of the dominant kernel per launch (rocprofv3 FETCH_SIZE x2 + "
+                                 "WRITE_SIZE of a committed profile of these exact kernel sources, else the bytes "
+                                 "the kernel moves by design) / its HIP-event launch time / 8 TB/s; step.frac = "
+                                 "the same over all kernels of one step and the wall time per step; "
+                                 "frac_contract = SURVEY 8(d) trellis-materialising bytes (18 S + 28 per sample) "
+                                 "/ step time / peak: > 1 because no engine here writes the trellis"},
             "detail": {"viterbi_Msamples_s": T / t_vit / 1e6, "estep_Msamples_s": T / t_est / 1e6,
                        "kernel_ms": {k: round(v, 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1])},
                        "sum_kernel_ms_per_step": step_ms_kernels,
                        "em_iteration_ms": em_ms, "em_sigma_after_10": em_sigma,
-                       "multi_channel": {"channels_per_gpu": args.channels, "Msamples_s": mc} if mc else None,
+                       "multi_channel": mc, "config4_share": cfg4, "config5_shape": cfg5,
                        "overlap_decode": ov,
                        "diag": diag[:7], "workspace_GB": info["workspace_bytes"] / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline and not args.quick:
             res["cpu_baseline"] = cpu_baseline(H, N, K, temps, pp, sigma)
+        # a step whose chain boundaries are not all certified is not a measurement of the metric
+        res["valid"] = bool(diag[0] == 0 and diag[3] == 0 and diag[5] == 0)
+        res["detail"]["near_ties_on_path"] = diag[7] if len(diag) > 7 else None
         print(json.dumps(res))
+        if not res["valid"]:
+            print("bench: boundary certificates failed (diag %s): the line above is INVALID" % (diag,), file=sys.stderr)
+            plan.close()
+            sys.exit(3)
     plan.close()
     if dist is not None:
         dist.destroy_process_group()

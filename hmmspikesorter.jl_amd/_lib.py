@@ -53,6 +53,10 @@ SIGNATURES = {
     "hmmsort_plan_create": (_int, [C.POINTER(_vp), _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp,
                                    _f64]),
     "hmmsort_plan_set_model": (_int, [_vp, _vp, _i64, _vp, _f64]),
+    "hmmsort_plan_create_batched": (_int, [C.POINTER(_vp), _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64,
+                                           _vp, _vp]),
+    "hmmsort_plan_channels": (_i64, [_vp]),
+    "hmmsort_plan_set_model_channel": (_int, [_vp, _i64, _vp, _i64, _vp, _f64]),
     "hmmsort_plan_destroy": (_int, [_vp]),
     "hmmsort_plan_info": (_int, [_vp, _pi64, _pi64, _pi64, _pi64, _pi64]),
     "hmmsort_plan_bind": (_int, [_vp, _vp, _vp]),

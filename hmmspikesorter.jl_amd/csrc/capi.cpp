@@ -205,12 +205,70 @@ int hmmsort_plan_create(hmmsort_plan **plan_out, int64_t T, const int16_t *state
     return plan_create_engine(plan_out, T, states, N, K, S, tr, R, mu, sigma, options().engine);
 }
 
+// Batched plan: C recording channels of the same length and model SHAPE, each with its own transition
+// values / templates / sigma (the reference sorts one channel per call with its own model,
+// src/hmmsort.jl:79-83); one set of launches sweeps all channels (chains = channels x chains per channel).
+int hmmsort_plan_create_batched(hmmsort_plan **plan_out, int64_t C, int64_t T, const int16_t *states,
+                                int64_t N, int64_t K, int64_t S, const hmm_trans *tr, int64_t R,
+                                const double *mu, const double *sigma)
+{
+    HS_CHECK(plan_out, HMMSORT_EINVAL, "plan_create_batched: null output pointer");
+    *plan_out = nullptr;
+    HS_CHECK(C >= 1 && C <= 4096 && T >= 1 && tr && mu && sigma, HMMSORT_EINVAL,
+             "plan_create_batched: bad argument (C = %lld, T = %lld)", (long long)C, (long long)T);
+    int rc = need_device();
+    if (rc) return rc;
+    hmmsort_plan *p = new hmmsort_plan();
+    PlanGuard guard{p};
+    p->T = T;
+    p->C = C;
+    p->models.resize(C);
+    for (int64_t ch = 0; ch < C; ch++) {
+        rc = build_host_model(p->models[ch], states, N, K, S, tr + ch * R, R, mu + ch * K * N, sigma[ch]);
+        if (rc) return rc;
+    }
+    p->model = p->models[0];
+    std::string why;
+    if (!wave_supported(p->model, T, &why)) {
+        set_error("plan_create_batched needs the wave engine: %s", why.c_str());
+        return HMMSORT_EUNSUP;
+    }
+    p->engine = HMMSORT_ENGINE_WAVE;
+    rc = wave_create(&p->wave, p->models, T, options().block, options().halo);
+    if (rc) return rc;
+    guard.p = nullptr;
+    *plan_out = p;
+    return HMMSORT_OK;
+}
+
+int64_t hmmsort_plan_channels(const hmmsort_plan *p) { return p ? p->C : 0; }
+
+int hmmsort_plan_set_model_channel(hmmsort_plan *p, int64_t channel, const hmm_trans *tr, int64_t R,
+                                   const double *mu, double sigma)
+{
+    HS_CHECK(p && tr && mu, HMMSORT_EINVAL, "plan_set_model_channel: null argument");
+    HS_CHECK(p->wave, HMMSORT_EUNSUP, "plan_set_model_channel: needs a wave-engine plan");
+    HS_CHECK(channel >= 0 && channel < p->C, HMMSORT_EINVAL, "plan_set_model_channel: channel %lld outside 0..%lld",
+             (long long)channel, (long long)p->C - 1);
+    HostModel m;
+    std::vector<int16_t> st = p->model.states;
+    int rc = build_host_model(m, st.data(), p->model.N, p->model.K, p->model.S, tr, R, mu, sigma);
+    if (rc) return rc;
+    HS_CHECK(m.ring.valid, HMMSORT_EUNSUP, "plan_set_model_channel: new model is not a ring model");
+    if ((rc = wave_set_model(p->wave, (int)channel, m))) return rc;
+    p->models[channel] = m;
+    if (channel == 0) p->model = std::move(m);
+    return HMMSORT_OK;
+}
+
 int hmmsort_plan_set_model(hmmsort_plan *p, const hmm_trans *tr, int64_t R, const double *mu,
                            double sigma)
 {
     HS_CHECK(p && tr && mu, HMMSORT_EINVAL, "plan_set_model: null argument");
-    HS_CHECK(R == p->model.R, HMMSORT_EINVAL, "plan_set_model: R changed (%lld -> %lld)",
-             (long long)p->model.R, (long long)R);
+    // the ring engines take the list apart into junction constants, so a list that has lost the entry
+    // transitions of a vanished template (types.jl:121 keeps finite entries only) fits the same plan
+    HS_CHECK(R == p->model.R || p->wave || p->ring, HMMSORT_EINVAL,
+             "plan_set_model: R changed (%lld -> %lld)", (long long)p->model.R, (long long)R);
     HostModel m;
     std::vector<int16_t> st = p->model.states;
     int rc = build_host_model(m, st.data(), p->model.N, p->model.K, p->model.S, tr, R, mu, sigma);

@@ -232,13 +232,16 @@ int build_host_model(HostModel &m, const int16_t *states, int64_t N, int64_t K, 
     return HMMSORT_OK;
 }
 
-// Is the transition list exactly the no-overlap ring pattern (in the reference's order)?
+// Is the transition list the no-overlap ring pattern (in the reference's order)?  The reference keeps
+// finite entries only (types.jl:121), so a template whose entry log-probability has become -Inf has lost
+// its N entry transitions (silent -> (a,1) and every (b,L) -> (a,1)): those are accepted as missing and
+// recorded as -Inf.  Everything else (silent -> silent, ring interiors, (a,L) -> silent) must be there.
 int analyze_ring(const HostModel &m, RingModel &ring)
 {
     ring = RingModel();
     const int64_t N = m.N, L = m.K - 1, S = m.S, R = m.R;
     if (L < 1 || S != 1 + N * L) return 0;
-    if (R != N * (L - 1) + N * N + N + 1) return 0;
+    if (R > N * (L - 1) + N * N + N + 1) return 0;
     // state table must be the single-active enumeration
     for (int64_t a = 0; a < N; a++)
         for (int64_t k = 1; k <= L; k++) {
@@ -251,17 +254,21 @@ int analyze_ring(const HostModel &m, RingModel &ring)
     for (int64_t l = 0; l < N; l++)
         if (m.states[l] != 1) return 0;
     ring.N = (int)N; ring.L = (int)L;
-    ring.c0.assign(N, 0); ring.cint.assign(N * L, 0); ring.cend.assign(N, 0); ring.cx.assign(N * N, 0);
+    ring.c0.assign(N, -INFINITY); ring.cint.assign(N * L, 0); ring.cend.assign(N, 0);
+    ring.cx.assign(N * N, -INFINITY);
     int64_t r = 0;
+    // a mandatory transition must be the next list entry; an entry transition may be absent
     auto expect = [&](int64_t s, int64_t d, double *out) {
         if (r >= R || m.tr[r].src != s + 1 || m.tr[r].dst != d + 1) return false;
         *out = m.tr[r].lp;
         r++;
         return true;
     };
+    auto optional = [&](int64_t s, int64_t d, double *out) {
+        if (r < R && m.tr[r].src == s + 1 && m.tr[r].dst == d + 1) { *out = m.tr[r].lp; r++; }
+    };
     if (!expect(0, 0, &ring.c00)) return 0;
-    for (int64_t a = 0; a < N; a++)
-        if (!expect(0, 1 + a * L, &ring.c0[a])) return 0;
+    for (int64_t a = 0; a < N; a++) optional(0, 1 + a * L, &ring.c0[a]);
     for (int64_t a = 0; a < N; a++) {
         for (int64_t k = 1; k < L; k++)
             if (!expect(1 + a * L + (k - 1), 1 + a * L + k, &ring.cint[a * L + k])) return 0;
@@ -269,7 +276,7 @@ int analyze_ring(const HostModel &m, RingModel &ring)
         if (!expect(e, 0, &ring.cend[a])) return 0;
         for (int64_t b = 0; b < N; b++) {
             if (b == a) continue;
-            if (!expect(e, 1 + b * L, &ring.cx[a * N + b])) return 0;
+            optional(e, 1 + b * L, &ring.cx[a * N + b]);
         }
     }
     if (r != R) return 0;

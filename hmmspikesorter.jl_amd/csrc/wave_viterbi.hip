@@ -22,10 +22,10 @@
 // differs from the reference's by rounding at the 1e-13 level (pre-summed ring scores, scan order,
 // per-chain offsets instead of the reference's O(t) cumulative sum, whose own rounding unit is
 // larger).  Every decision records whether its winner beat the runner-up by less than
-// thr = 16 (L+2) ulp(|T1|max) + 4e-9 -- a bound on what the reference's own rounding plus ours can
-// move a difference between two paths -- and the backtrace counts the flagged decisions ON THE
-// DECODED PATH in diag[7]: 0 means the path is the reference's bit for bit; otherwise the host entry
-// points decode with the strict engine.
+// thr = 16 sqrt(L+2) ulp(|T1|max) + 4e-9 (wave_thr below: many standard deviations of what the
+// reference's own rounding can move a difference between two paths) -- and the backtrace counts the
+// flagged decisions ON THE DECODED PATH in diag[7]: 0 means the path is the reference's bit for bit;
+// otherwise the host entry points decode with the strict engine.
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
@@ -42,6 +42,13 @@ struct WIn {
     double R[N];
 };
 
+// Near-tie threshold.  The reference compares candidates T1[k,t-1] + lp whose values have grown to
+// |T1| ~ t |A - 1/2| (ulp 1e-9 after 1e7 samples, 1.5e-8 after 1e8); two paths that separated d steps
+// ago carry independent rounding errors of d additions each, so the reference's own decision is noise
+// once the true margin is below sigma = ulp sqrt(d/6), d ~ 2(L+1) for one ring.  A decision is flagged
+// when its margin (in this engine's per-chain frame, rounding ~1e-13) is below
+//     thr = 16 sqrt(L+2) ulp(|T1|max) + 4e-9    (~27 sigma for one ring, 8 sigma for ten rings in a row),
+// the 4e-9 covering the tolerance of the chain-boundary certificate.
 __device__ __forceinline__ double wave_thr(const WaveGeom &g, const WaveConst &K, const double *__restrict__ ysum, int ch)
 {
     // largest magnitude the reference's trellis reaches: |sum_t (A - d^2/den + lp)| <= ...
@@ -49,7 +56,7 @@ __device__ __forceinline__ double wave_thr(const WaveGeom &g, const WaveConst &K
     const double s1 = ysum[2 * ch], s2 = ysum[2 * ch + 1];
     const double sq = fmax((s2 - 2.0 * K.mean0 * s1) + T * K.mean0 * K.mean0, 0.0);
     const double mmax = fabs(K.A) * T + sq / K.den + fabs(K.c00) * T + 1.0;
-    return ldexp(16.0 * (double)(g.L + 2), ilogb(mmax) - 52) + 4.0 * kVitTol;
+    return ldexp(16.0 * sqrt((double)(g.L + 2)), ilogb(mmax) - 52) + 4.0 * kVitTol;
 }
 
 // UC ("uniform cx"): the log-probability of (b,L) -> (a,1) does not depend on b -- true for every

@@ -31,6 +31,36 @@ class Plan:
                                         ptr(tr), len(tr), ptr(mu), float(sigma)))
         self.K, self.N, self.S = lA.K, lA.N, lA.nstates
 
+    @classmethod
+    def batched(cls, T, lAs, mus, sigmas):
+        """C channels of length T with per-channel models of one shape (hmmsort_plan_create_batched).
+        Device buffers of every call are channel-major: y [C][T], x [C][T], ll [C], stats [C][len]."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(None)
+        self.T = int(T)
+        lA = lAs[0]
+        self.lA = lA
+        nC = len(lAs)
+        R = len(lA.transitions)
+        tr = np.ascontiguousarray(np.stack([np.ascontiguousarray(a.transitions, dtype=TRANS_DTYPE) for a in lAs]))
+        assert tr.shape == (nC, R), "batched plan: every channel needs the same transition count"
+        mu = np.ascontiguousarray(np.stack([np.asfortranarray(m, dtype=np.float64).ravel(order="F") for m in mus]))
+        sg = np.ascontiguousarray(sigmas, dtype=np.float64)
+        st = np.asfortranarray(lA.states, dtype=np.int16)
+        check(lib().hmmsort_plan_create_batched(C.byref(self._h), nC, self.T, ptr(st), lA.N, lA.K, lA.nstates,
+                                                ptr(tr), R, ptr(mu), ptr(sg)))
+        self.K, self.N, self.S = lA.K, lA.N, lA.nstates
+        self.C = nC
+        return self
+
+    def channels(self):
+        return int(lib().hmmsort_plan_channels(self._h))
+
+    def set_model_channel(self, ch, lA, mu, sigma):
+        mu = np.asfortranarray(mu, dtype=np.float64)
+        tr = np.ascontiguousarray(lA.transitions, dtype=TRANS_DTYPE)
+        check(lib().hmmsort_plan_set_model_channel(self._h, int(ch), ptr(tr), len(tr), ptr(mu), float(sigma)))
+
     def close(self):
         if self._h:
             lib().hmmsort_plan_destroy(self._h)

@@ -150,7 +150,24 @@ typedef struct hmmsort_plan hmmsort_plan;
 int hmmsort_plan_create(hmmsort_plan **plan_out, int64_t T, const int16_t *states, int64_t N,
                         int64_t K, int64_t S, const hmm_trans *tr, int64_t R, const double *mu,
                         double sigma);
-/* Replace transitions / mu / sigma (same N, K, S, R) -- e.g. between EM iterations. */
+/* Batched plan (SURVEY 8b "batched variants with a leading channel count C"): C recording channels of
+ * the same length T and the same model shape, each with its own transition values, templates and sigma
+ * (the reference sorts one channel per call with that channel's model, src/hmmsort.jl:79-83).
+ *   tr: C lists of R records, mu: C matrices of K x N, sigma: C values.
+ * Every plan call then takes channel-major device buffers: d_y [C][T], d_x [C][T], d_ll [C],
+ * d_stats [C][hmmsort_plan_stats_len()], d_out [C][K*N + 1 + N + S]; one set of launches sweeps all
+ * channels (chains = channels x chains per channel), so short channels still fill the GPU.  Summing the
+ * per-channel statistics before hmmsort_plan_mstep gives pooled templates (an extension the reference
+ * lacks).  Wave engine only (HMMSORT_EUNSUP otherwise); diagnostics are summed over the channels. */
+int hmmsort_plan_create_batched(hmmsort_plan **plan_out, int64_t C, int64_t T, const int16_t *states,
+                                int64_t N, int64_t K, int64_t S, const hmm_trans *tr, int64_t R,
+                                const double *mu, const double *sigma);
+int64_t hmmsort_plan_channels(const hmmsort_plan *plan);
+/* hmmsort_plan_set_model for one channel of a batched plan */
+int hmmsort_plan_set_model_channel(hmmsort_plan *plan, int64_t channel, const hmm_trans *tr, int64_t R,
+                                   const double *mu, double sigma);
+/* Replace transitions / mu / sigma (same N, K, S; R may shrink when a template has lost its entry
+ * transitions) -- e.g. between EM iterations. */
 int hmmsort_plan_set_model(hmmsort_plan *plan, const hmm_trans *tr, int64_t R, const double *mu,
                            double sigma);
 int hmmsort_plan_destroy(hmmsort_plan *plan);
