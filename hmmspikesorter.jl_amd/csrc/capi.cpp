@@ -418,6 +418,18 @@ int hmmsort_plan_debug_record(hmmsort_plan *p, double *out64)
     return HMMSORT_OK;
 }
 
+// debugging aid (not part of the documented ABI): copy an internal per-sample array of a wave plan
+// which: 0 FA0 (log alpha silent), 1 FREF, 2 FV (N x T), 3 rho (N x T), 4 Rf (N x T)
+int hmmsort_plan_debug_array(hmmsort_plan *p, int which, double *out, int64_t n)
+{
+    HS_CHECK(p && out && p->wave, HMMSORT_EINVAL, "plan_debug_array: needs a wave plan");
+    HS_HIP(hipDeviceSynchronize());
+    const WaveDev *w = p->wave;
+    const double *src = which == 0 ? w->FA0 : which == 1 ? w->FREF : which == 2 ? w->FV : which == 3 ? w->rho : w->Rf;
+    HS_HIP(hipMemcpy(out, src, n * sizeof(double), hipMemcpyDeviceToHost));
+    return HMMSORT_OK;
+}
+
 int hmmsort_plan_profile(hmmsort_plan *p, int enable)
 {
     HS_CHECK(p, HMMSORT_EINVAL, "plan_profile: null plan");

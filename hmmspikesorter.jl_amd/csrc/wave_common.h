@@ -81,6 +81,7 @@ struct WaveDev {
     int16_t *d_states = nullptr;      // N x S
     // per-sample arrays, natural layout [C][...][T]
     double *Rf = nullptr;             // C x N x T ring scores
+    double *W2 = nullptr;             // C x T: sum of y^2 over the L samples from t (0 past the end)
     double *virt = nullptr;           // C x N x (L+1) virtual onsets V[a][j]
     double *ysum = nullptr;           // C x 2: sum y, sum y^2
     uint32_t *psi = nullptr;          // PW x C x T
@@ -97,7 +98,7 @@ struct WaveDev {
     double *bpre = nullptr, *bown = nullptr;   // C*nch x (1 + L*(N+1)): backward boundary values (warm-up / own)
     double *rho = nullptr;            // C x N x T onset posteriors
     double *Zc = nullptr;             // C*nch
-    double *partS = nullptr;          // C*nch x (2N+3)
+    double *partS = nullptr;          // C*nch x (3N+3)
     double *partG = nullptr;          // gsum partials
     double *yhead = nullptr;          // C x (N*L + 2): Yn_a(t), t < L (logs) | lb0(0) | z0
     double *extra = nullptr;          // C x 3*N*L
@@ -173,6 +174,32 @@ __device__ __forceinline__ void scan_maxplus(double &a, double &b)
     HS_MP_STEP(0x111, 0xF) HS_MP_STEP(0x112, 0xF) HS_MP_STEP(0x114, 0xF) HS_MP_STEP(0x118, 0xF)
     HS_MP_STEP(0x142, 0xA) HS_MP_STEP(0x143, 0xC)
 #undef HS_MP_STEP
+}
+
+// The same scan in single precision, for the forward/backward sweeps: there the max-plus envelope M_t is
+// only the SCALE of the linear recursion (any value within a few hundred nats of the true log value
+// works, tests/wave_model.py), and it is used consistently (the rounded float, converted back) in
+// every exponent, so its precision does not enter the results.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_movf(float old, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROWMASK, 0xF, false));
+}
+__device__ __forceinline__ void scan_maxplus_f32(float &a, float &b)
+{
+#define HS_MPF_STEP(CTRL, RM)                                                     \
+    {                                                                             \
+        const float al = dpp_movf<CTRL, RM>(0.0f, a), bl = dpp_movf<CTRL, RM>(-INFINITY, b); \
+        b = fmaxf(bl + a, b);                                                     \
+        a = al + a;                                                               \
+    }
+    HS_MPF_STEP(0x111, 0xF) HS_MPF_STEP(0x112, 0xF) HS_MPF_STEP(0x114, 0xF) HS_MPF_STEP(0x118, 0xF)
+    HS_MPF_STEP(0x142, 0xA) HS_MPF_STEP(0x143, 0xC)
+#undef HS_MPF_STEP
+}
+__device__ __forceinline__ float lane_prevf(float v, float carry)
+{
+    return dpp_movf<0x138, 0xF>(carry, v);
 }
 
 // inclusive scan of f_j(x) = a_j * x + b_j.  Identity: (1, 0).

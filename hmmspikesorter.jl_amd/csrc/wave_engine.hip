@@ -195,6 +195,7 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
     A(&r->d_ctab, C * (1 + 2 * N + N * N + N * L));
     A(&r->d_states, N * m.S);
     A(&r->Rf, N * CT);
+    A(&r->W2, CT);
     A(&r->virt, C * N * (L + 1));
     A(&r->ysum, 2 * C);
     A(&r->psi, (int64_t)g.PW * CT);
@@ -213,9 +214,9 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
     A(&r->bown, nchT * (1 + L * (N + 1)));
     A(&r->rho, N * CT);
     A(&r->Zc, nchT);
-    A(&r->partS, nchT * (2 * N + 3));
+    A(&r->partS, nchT * (3 * N + 3));
     r->gparts = (int)((T + 4095) / 4096);
-    A(&r->partG, (int64_t)C * r->gparts * 2 * N * L);
+    A(&r->partG, (int64_t)C * r->gparts * N * L);
     A(&r->yhead, C * (N * L + 2));
     A(&r->extra, C * 3 * N * L);
     A(&r->pp, C * m.S);
@@ -236,8 +237,8 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
         (void)hipMemset(r->bown, 0xFF, nchT * (1 + L * (N + 1)) * 8);
         (void)hipMemset(r->rho, 0xFF, N * CT * 8);
         (void)hipMemset(r->Zc, 0xFF, nchT * 8);
-        (void)hipMemset(r->partS, 0xFF, nchT * (2 * N + 3) * 8);
-        (void)hipMemset(r->partG, 0xFF, (int64_t)C * r->gparts * 2 * N * L * 8);
+        (void)hipMemset(r->partS, 0xFF, nchT * (3 * N + 3) * 8);
+        (void)hipMemset(r->partG, 0xFF, (int64_t)C * r->gparts * N * L * 8);
         (void)hipMemset(r->yhead, 0xFF, C * (N * L + 2) * 8);
     }
     if (hipMemset(r->diag, 0, 8 * sizeof(int64_t)) != hipSuccess ||
@@ -272,7 +273,7 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
 void wave_destroy(WaveDev *r)
 {
     if (!r) return;
-    void *ptrs[] = {r->d_cst, r->d_mean, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->Rf, r->virt, r->ysum,
+    void *ptrs[] = {r->d_cst, r->d_mean, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->Rf, r->W2, r->virt, r->ysum,
                     r->psi, r->vpre, r->vend, r->vfail, r->bstate, r->redo, r->final_state, r->part, r->FA0,
                     r->FV, r->FREF, r->fpre, r->bpre, r->bown, r->rho, r->Zc, r->partS, r->partG, r->yhead,
                     r->extra, r->pp, r->diag, r->dbg, r->trash};
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(256) void kw_prepass(WaveGeom g, const WaveConst *_
                                                   const double *__restrict__ mean,
                                                   const double *__restrict__ cint,
                                                   const double *__restrict__ msq,
-                                                  double *__restrict__ Rf, double *__restrict__ ysum)
+                                                  double *__restrict__ Rf, double *__restrict__ W2,
+                                                  double *__restrict__ ysum)
 {
     constexpr int kPreRows = pre_rows<N>(), kPreTile = 256 * kPreRows;
     extern __shared__ double ly[];  // y tile: kPreTile + L | means: N*L (read as broadcasts)
@@ -364,6 +366,7 @@ __global__ __launch_bounds__(256) void kw_prepass(WaveGeom g, const WaveConst *_
                 const double ss = (ysq[r] - 2.0 * dot[r][a]) + msq[((int64_t)ch * N + a) * (L + 1) + kmax];
                 Rf[((int64_t)ch * N + a) * T + t] = cint[((int64_t)ch * N + a) * (L + 1) + kmax] - ss / den;
             }
+            W2[(int64_t)ch * T + t] = ysq[r];   // for sigma: sum_k G2(a,k) = sum_t' rho_a(t') W2(t')
             const double yv = ly[threadIdx.x + 256 * r];
             s1 += yv; s2 = __builtin_fma(yv, yv, s2);
         }
@@ -424,7 +427,7 @@ int wave_prepare(WaveDev *r, const double *d_y, hipStream_t st)
         constexpr int kPreTile = 256 * pre_rows<N>();
         hipLaunchKernelGGL((kw_prepass<N>), dim3((unsigned)((g.T + kPreTile - 1) / kPreTile), g.C), dim3(256),
                            (size_t)(kPreTile + g.L + N * g.L) * sizeof(double), st, g, r->d_cst, d_y, r->d_mean, r->d_cint,
-                           r->d_msq, r->Rf, r->ysum);
+                           r->d_msq, r->Rf, r->W2, r->ysum);
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
     });
@@ -484,19 +487,23 @@ __global__ void kw_selftest_scans(const double *__restrict__ in, double *__restr
     out[512 + lane] = lane_prev(in[lane], 123.5);
     out[576 + lane] = lane_prev_ref(in[lane], 123.5, lane);
     out[640 + lane] = wave_bcast(in[lane], 63);
+    float fa = (float)in[lane], fb = (float)in[64 + lane];
+    scan_maxplus_f32(fa, fb);
+    out[704 + lane] = fa; out[768 + lane] = fb;
+    out[832 + lane] = lane_prevf((float)in[lane], 7.25f);
 }
 }  // namespace hmmsort
 
-extern "C" int hmmsort_selftest_scans(const double *in256, double *out704)
+extern "C" int hmmsort_selftest_scans(const double *in256, double *out896)
 {
     using namespace hmmsort;
     double *di = nullptr, *dout = nullptr;
     HS_HIP(hipMalloc((void **)&di, 256 * sizeof(double)));
-    HS_HIP(hipMalloc((void **)&dout, 704 * sizeof(double)));
+    HS_HIP(hipMalloc((void **)&dout, 896 * sizeof(double)));
     HS_HIP(hipMemcpy(di, in256, 256 * sizeof(double), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(kw_selftest_scans, dim3(1), dim3(64), 0, nullptr, di, dout);
     HS_HIP(hipDeviceSynchronize());
-    HS_HIP(hipMemcpy(out704, dout, 704 * sizeof(double), hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(out896, dout, 896 * sizeof(double), hipMemcpyDeviceToHost));
     (void)hipFree(di); (void)hipFree(dout);
     return HMMSORT_OK;
 }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
     for (int i = lane; i < 2 * N * (RB + 1); i += 64) DLv[i] = 0.0;
     {
         const WaveConst &Kg = cst[ch];
-        if (lane == 0) { KC[0] = Kg.sc0; KC[1] = Kg.mean0; KC[2] = Kg.den; KC[3] = Kg.P00; KC[4] = fexp(-Kg.sc0); }
+        if (lane == 0) { KC[0] = Kg.sc0; KC[1] = Kg.mean0; KC[2] = 1.0 / Kg.den; KC[3] = Kg.P00; KC[4] = fexp(-Kg.sc0); }
         if (lane < N) { KC[KSC + lane] = Kg.sc[lane]; KC[KCP0 + lane] = Kg.CP0[lane]; KC[KPEND + lane] = Kg.PEND[lane]; }
         if (UC) { if (lane < N) KC[KCPX + lane] = Kg.CPXin[lane]; }
         else for (int i = lane; i < N * N; i += 64) KC[KCPX + i] = Kg.CPXT[i];
@@ -104,14 +104,16 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
             }
         }
         const double d0 = yc[0] - KC[1];
-        M = -((d0 * d0) / KC[2]);
+        const double q00 = -((d0 * d0) * KC[2]);
+        M = (double)(float)q00;                           // float-representable scale, remainder in x
+        x = fexp(q00 - M);
         if (lane < N) {
             const double f0 = fexp(-KC[KSC + lane]);
             DLv[lane * (RB + 1) + L] = f0;
             DLs[lane * (RB + 1) + L] = KC[KSC + lane] + Rc[(int64_t)lane * T];
             FVc[(int64_t)lane * T] = f0;
         }
-        if (lane == 0) { FAc[0] = M; FRc[0] = 0.0; }
+        if (lane == 0) { FAc[0] = q00; FRc[0] = 0.0; }
     } else {
         tinit = tc - g.Hw;
         M = 0.0;
@@ -149,12 +151,14 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
             e = fmax(e, scale_of(v[a], E[a]));
         }
         const double dd = d.y - KC[1];
-        const double q0 = -((dd * dd) / KC[2]);
-        double sa = live ? sc0 + q0 : 0.0;
-        double sb = live ? e + q0 : -INFINITY;
-        scan_maxplus(sa, sb);
-        const double Mt = fmax(M + sa, sb);
-        const double Mprev = lane_prev(Mt, M);
+        const double q0 = -((dd * dd) * KC[2]);           // KC[2] = 1/den: 1 ulp from the reference's division (bar here: 1e-6)
+        float fa = live ? (float)(sc0 + q0) : 0.0f;
+        float fb = live ? (float)(e + q0) : -INFINITY;
+        scan_maxplus_f32(fa, fb);                         // the envelope is a scale: single precision
+        const float Mf = (float)M;                        // exact: the carry is kept float-representable
+        const float Mtf = fmaxf(Mf + fa, fb);
+        const double Mt = (double)Mtf;
+        const double Mprev = (double)lane_prevf(Mtf, Mf);  // cross-lane moves must run with all lanes enabled
         const double ref = Mt - q0;
         E[N] = (Mprev + sc0) - ref;
 #pragma unroll
@@ -216,10 +220,16 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
                 if (t == tc - 1) rec[0] = Mt + flog(xt);
             }
         }
-        x = wave_bcast(xt, 63);
-        M = wave_bcast(Mt, 63);
+        // carry from the last LIVE lane: an idle lane's prefix is the same sum in another association, and
+        // (x, M) must be the pair of one lane
+        x = wave_bcast(xt, nact - 1);
+        M = wave_bcast(Mt, nact - 1);
         const int ee = x > 0.0 ? ilogb(x) : 0;
-        if (ee >= 32 || ee <= -32) { x = ldexp(x, -ee); M += (double)ee * kLn2; }
+        if (ee >= 32 || ee <= -32) {   // renormalise the carry: x exp(M) unchanged, M stays a float value
+            const double Mx = M + (double)ee * kLn2, Mn = (double)(float)Mx;
+            x = ldexp(x, -ee) * fexp(Mx - Mn);
+            M = Mn;
+        }
         rs += W; rs = rs >= RB ? rs - RB : rs;
         ws += W; ws = ws >= RB ? ws - RB : ws;
     };
@@ -261,6 +271,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
 template <int N>
 struct BIn {
     double y1, y0;    // y(t+1), y(t)
+    double w2;        // W2(t+1)
     double R[N];      // R_a(t+1)
     double fv[N];     // fv_a(t+1)
     double fref, la0; // fref(t+1), la0(t)
@@ -274,6 +285,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
                                                             const double *__restrict__ FV,
                                                             const double *__restrict__ FREF,
                                                             const double *__restrict__ fpre,
+                                                            const double *__restrict__ W2,
                                                             double *__restrict__ rho, double *__restrict__ partS,
                                                             double *__restrict__ Zc, double *__restrict__ bpre,
                                                             double *__restrict__ bown, double *__restrict__ yhead,
@@ -295,6 +307,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
     const double *Rc = Rf + (int64_t)ch * N * T;
     const double *FAc = FA0 + (int64_t)ch * T, *FRc = FREF + (int64_t)ch * T, *FVc = FV + (int64_t)ch * N * T;
     double *rhoc = rho + (int64_t)ch * N * T;
+    const double *W2c = W2 + (int64_t)ch * T;
     const int64_t FR = 1 + (int64_t)L * (N + 1);
     const double la0pre = c > 0 ? fpre[cg * FR] : 0.0;
     double *recp = bpre + cg * FR, *reco = bown + cg * FR;
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
     for (int i = lane; i < RB + 1; i += 64) DLs[i] = 0.0;
     {
         const WaveConst &Kg = cst[ch];
-        if (lane == 0) { KC[0] = Kg.sc0; KC[1] = Kg.mean0; KC[2] = Kg.den; KC[3] = Kg.P00; }
+        if (lane == 0) { KC[0] = Kg.sc0; KC[1] = Kg.mean0; KC[2] = 1.0 / Kg.den; KC[3] = Kg.P00; }
         if (lane < N) { KC[KSC + lane] = Kg.sc[lane]; KC[KCP0 + lane] = Kg.CP0[lane]; KC[KPEND + lane] = Kg.PEND[lane]; }
         if (UC) { if (lane < N) KC[KCPX + lane] = Kg.CPXin[lane]; }
         else for (int i = lane; i < N * N; i += 64) KC[KCPX + i] = Kg.CPX[i];
@@ -312,9 +325,9 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
     __syncthreads();
 
     double Mb = 0.0, xb = 1.0, z = 0.0;
-    double sx[N], ra[N], s_all = 0.0, s_m = 0.0, s_y2 = 0.0;
+    double sx[N], ra[N], s2[N], s_all = 0.0, s_m = 0.0, s_y2 = 0.0;
 #pragma unroll
-    for (int a = 0; a < N; a++) { sx[a] = 0.0; ra[a] = 0.0; }
+    for (int a = 0; a < N; a++) { sx[a] = 0.0; ra[a] = 0.0; s2[a] = 0.0; }
 
     const int n_warm = (int)(te - tend);                 // steps t = te-2 .. tstar
     const int n_total = n_warm + nc;                     // ... then tstar-1 .. tc-1
@@ -336,6 +349,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
         const int64_t tz = t < 0 ? 0 : t;
         d.y1 = yc[t1];
         d.y0 = yc[tz];
+        d.w2 = W2c[t1];
         d.fref = FRc[t1];
         d.la0 = FAc[tz];
 #pragma unroll
@@ -370,12 +384,14 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
             e = fmax(e, scale_of(vb[a], E[a]));
         }
         const double dd = d.y1 - KC[1];
-        const double q1 = -((dd * dd) / KC[2]);
-        double sa = live ? q1 + sc0 : 0.0;
-        double sb = live ? e : -INFINITY;
-        scan_maxplus(sa, sb);
-        const double Mt = fmax(Mb + sa, sb);
-        const double Mnext = lane_prev(Mt, Mb);
+        const double q1 = -((dd * dd) * KC[2]);           // KC[2] = 1/den
+        float fa = live ? (float)(q1 + sc0) : 0.0f;
+        float fb = live ? (float)e : -INFINITY;
+        scan_maxplus_f32(fa, fb);                         // the envelope is a scale: single precision
+        const float Mbf = (float)Mb;                      // exact: the carry is kept float-representable
+        const float Mtf = fmaxf(Mbf + fa, fb);
+        const double Mt = (double)Mtf;
+        const double Mnext = (double)lane_prevf(Mtf, Mbf);
         E[N] = ((Mnext + q1) + sc0) - Mt;
 #pragma unroll
         for (int a = 0; a < N; a++) E[a] = vb[a] > 0.0 ? fmin(E[a] - Mt, 700.0) : -INFINITY;
@@ -449,6 +465,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
                 const double rv = own1 ? (d.fv[a] * wa[a]) * gg[1] : 0.0;
                 *(live ? rhoc + (int64_t)a * T + t1 : trash + 64 * a + lane) = rv;
                 ra[a] += bulk ? rv : 0.0;
+                s2[a] = __builtin_fma(rv, d.w2, s2[a]);          // sum_k G2(a,k) (baumwelch.jl:302)
                 sx[a] += (own1 && t >= 0) ? wa[a] * gg[0] : 0.0;  // xi'_a(t+1): silent(t) -> (a,1)(t+1), :240
             }
             if (MODE == 2 && c == 0 && t < L && live && t >= 0) {   // head of the recording: virtual onsets, pp
@@ -462,10 +479,14 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
                 if (t == 0) yh[N * L] = Mt + lg[N];
             }
         }
-        xb = wave_bcast(xt, 63);
-        Mb = wave_bcast(Mt, 63);
+        xb = wave_bcast(xt, nact - 1);                   // the pair of the last live lane
+        Mb = wave_bcast(Mt, nact - 1);
         const int ee = xb > 0.0 ? ilogb(xb) : 0;
-        if (ee >= 32 || ee <= -32) { xb = ldexp(xb, -ee); Mb += (double)ee * kLn2; }
+        if (ee >= 32 || ee <= -32) {
+            const double Mx = Mb + (double)ee * kLn2, Mn = (double)(float)Mx;
+            xb = ldexp(xb, -ee) * fexp(Mx - Mn);
+            Mb = Mn;
+        }
     };
     // normaliser at tstar (all lanes return the same z) and gamma_tstar(silent)
     auto znorm = [&]() {
@@ -548,16 +569,16 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
     const int ko1 = nsteps - rk > kwarm ? nsteps - rk : kwarm;
     if (ko1 > kwarm) sweep(kwarm, ko1, std::integral_constant<int, 1>());
     if (nsteps > ko1) sweep(ko1, nsteps, std::integral_constant<int, 2>());
-    // per-chain partial sums -> partS[cg][2N+3] = sx | ra | s_all s_m s_y2
-    double *ps = partS + (int64_t)cg * (2 * N + 3);
+    // per-chain partial sums -> partS[cg][3N+3] = sx | ra | s2 | s_all s_m s_y2
+    double *ps = partS + (int64_t)cg * (3 * N + 3);
 #pragma unroll
     for (int a = 0; a < N; a++) {
-        const double v1 = wave_sum(sx[a]), v2 = wave_sum(ra[a]);
-        if (lane == 0) { ps[a] = v1; ps[N + a] = v2; }
+        const double v1 = wave_sum(sx[a]), v2 = wave_sum(ra[a]), v3 = wave_sum(s2[a]);
+        if (lane == 0) { ps[a] = v1; ps[N + a] = v2; ps[2 * N + a] = v3; }
     }
     {
         const double v1 = wave_sum(s_all), v2 = wave_sum(s_m), v3 = wave_sum(s_y2);
-        if (lane == 0) { ps[2 * N] = v1; ps[2 * N + 1] = v2; ps[2 * N + 2] = v3; }
+        if (lane == 0) { ps[3 * N] = v1; ps[3 * N + 1] = v2; ps[3 * N + 2] = v3; }
     }
 }
 
@@ -669,7 +690,7 @@ __global__ __launch_bounds__(256) void kw_gsum_generic(WaveGeom g, const double 
     const double *yc = y + (int64_t)ch * T, *rc = rho + (int64_t)ch * N * T;
     const int p = threadIdx.x + 256 * blockIdx.z;   // this thread's (ring, phase) pair
     const int a = p < NL ? p / L : 0, k = p < NL ? p % L : 0;
-    double s1 = 0.0, s2 = 0.0;
+    double s1 = 0.0;
     for (int s0 = 0; s0 < kGsTile; s0 += kGsSub) {
         const int64_t tb = t0 + s0;
         if (tb >= T) break;
@@ -688,11 +709,10 @@ __global__ __launch_bounds__(256) void kw_gsum_generic(WaveGeom g, const double 
         for (int u = 0; u < kGsSub; u++) {
             const double r = lr[a * kGsSub + u], yv = ly[u + k];
             s1 = __builtin_fma(r, yv, s1);
-            s2 = __builtin_fma(r * yv, yv, s2);
         }
     }
-    double *out = partG + ((int64_t)ch * nparts + blockIdx.x) * 2 * NL;
-    if (p < NL) { out[p] = s1; out[NL + p] = s2; }
+    double *out = partG + ((int64_t)ch * nparts + blockIdx.x) * NL;
+    if (p < NL) out[p] = s1;
 }
 
 // Matrix-core statistics for few rings (N <= 8): the spike-triggered sums are a matrix product over
@@ -720,7 +740,10 @@ __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__re
     constexpr int YR = TR + 19 + LPT * (NT - 1);   // staged y rows per column (odd)
     constexpr int RS = RRP * NP + 2;               // rho column stride
     constexpr int TPS = (Bv + HS + TR - 1) / TR;   // tiles per column group
-    constexpr int NRH = (NP * RR * CW + 255) / 256, NYM = (CW * (YR - 1) + 255) / 256;
+    // staging indices are split with shifts only: rows per column rounded up to powers of two (the surplus
+    // rows are never loaded); integer divisions by 112 or 82 per element cost more than the MFMAs
+    constexpr int RRL = RR <= 64 ? 64 : (RR <= 128 ? 128 : (RR <= 256 ? 256 : 512)), YRL = (YR - 1) <= 128 ? 128 : ((YR - 1) <= 256 ? 256 : 512);
+    constexpr int NRH = NP * RRL * CW / 256, NYM = CW * YRL / 256;
     extern __shared__ double lds[];
     const int L = g.L, ch = blockIdx.y;
     const int64_t T = g.T;
@@ -729,9 +752,9 @@ __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__re
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lk = lane >> 4, lj = lane & 15, la = lj % NP, lsft = lj / NP;
     const double *yc = y + (int64_t)ch * T, *rc = rho + (int64_t)ch * N * T;
-    wg_d4 c1[NT], c2[NT];
+    wg_d4 c1[NT];
 #pragma unroll
-    for (int q = 0; q < NT; q++) { c1[q] = wg_d4{0.0, 0.0, 0.0, 0.0}; c2[q] = wg_d4{0.0, 0.0, 0.0, 0.0}; }
+    for (int q = 0; q < NT; q++) c1[q] = wg_d4{0.0, 0.0, 0.0, 0.0};
     int ntiles = 0;
     for (int sub = 0; sub < kGxSubs; sub++)
         if (((int64_t)blockIdx.x * kGxSubs + sub) * CW * Bv < T) ntiles += TPS;
@@ -742,19 +765,19 @@ __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__re
 #pragma unroll
         for (int k = 0; k < NRH; k++) {
             const int i = tid + k * 256;
-            const int a = i % NP, rest = i / NP, u = rest % RR, cc = rest / RR;
+            const int a = i % NP, u = (i / NP) % RRL, cc = i / (NP * RRL);
             const int row = s0 - HS + u;
             const int64_t t = (col0 + cc) * Bv + row;
-            const bool ok = i < NP * RR * CW && a < N && row >= 0 && row < Bv && t < T;
+            const bool ok = u < RR && a < N && row >= 0 && row < Bv && t < T;
             const double v = rc[ok ? (int64_t)a * T + t : 0];
             tr_[k] = ok ? v : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < NYM; k++) {
             const int i = tid + k * 256;
-            const int rr = i % (YR - 1), cc = i / (YR - 1);
+            const int rr = i % YRL, cc = i / YRL;
             const int64_t t = (col0 + cc) * Bv + s0 + rr;
-            const bool ok = i < CW * (YR - 1) && t < T;
+            const bool ok = rr < YR - 1 && t < T;
             const double v = yc[ok ? t : 0];
             ty_[k] = ok ? v : 0.0;
         }
@@ -765,13 +788,14 @@ __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__re
 #pragma unroll
         for (int k = 0; k < NRH; k++) {
             const int i = tid + k * 256;
-            const int a = i % NP, rest = i / NP, u = rest % RR, cc = rest / RR;
-            if (i < NP * RR * CW) lr[cc * RS + (u + u / 16) * NP + a] = tr_[k];
+            const int a = i % NP, u = (i / NP) % RRL, cc = i / (NP * RRL);
+            if (u < RR) lr[cc * RS + (u + u / 16) * NP + a] = tr_[k];
         }
 #pragma unroll
         for (int k = 0; k < NYM; k++) {
             const int i = tid + k * 256;
-            if (i < CW * (YR - 1)) ly[(i / (YR - 1)) * YR + i % (YR - 1)] = ty_[k];
+            const int rr = i % YRL, cc = i / YRL;
+            if (rr < YR - 1) ly[cc * YR + rr] = ty_[k];
         }
         __syncthreads();
         if (ti + 1 < ntiles) load_regs(ti + 1);   // in flight during the MFMAs
@@ -787,33 +811,29 @@ __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__re
                 for (int q = 0; q < NT; q++) {
                     const double a = lyc[ts * 4 + q * LPT];
                     c1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1[q], 0, 0, 0);
-                    c2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a * a, b, c2[q], 0, 0, 0);
                 }
             }
         }
     }
-    // sum the four waves' tiles: LDS [wave][NT][2][4 regs][64 lanes]
+    // sum the four waves' tiles: LDS [wave][NT][4 regs][64 lanes]
     __syncthreads();
     double *red = lds;
 #pragma unroll
     for (int q = 0; q < NT; q++) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            red[(((wv * NT + q) * 2 + 0) * 4 + r) * 64 + lane] = c1[q][r];
-            red[(((wv * NT + q) * 2 + 1) * 4 + r) * 64 + lane] = c2[q][r];
-        }
+        for (int r = 0; r < 4; r++) red[((wv * NT + q) * 4 + r) * 64 + lane] = c1[q][r];
     }
     __syncthreads();
     const int NL = N * L;
-    double *out = partG + ((int64_t)ch * nparts + blockIdx.x) * 2 * NL;
-    for (int e = tid; e < NT * 2 * 4 * 64; e += 256) {
-        const int ln = e & 63, r = (e >> 6) & 3, which = (e >> 8) & 1, q = e >> 9;
+    double *out = partG + ((int64_t)ch * nparts + blockIdx.x) * NL;
+    for (int e = tid; e < NT * 4 * 64; e += 256) {
+        const int ln = e & 63, r = (e >> 6) & 3, q = e >> 8;
         double v = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) v += red[(((w * NT + q) * 2 + which) * 4 + r) * 64 + ln];
+        for (int w = 0; w < 4; w++) v += red[((w * NT + q) * 4 + r) * 64 + ln];
         const int j = ln & 15, a = j % NP, sft = j / NP;
         const int lag = q * LPT + 16 * sft + (ln >> 4) + 4 * r;
-        if (a < N && lag < L) out[which * NL + a * L + lag] = v;
+        if (a < N && lag < L) out[a * L + lag] = v;
     }
 }
 
@@ -858,26 +878,33 @@ __global__ __launch_bounds__(64) void kw_edges(WaveGeom g, const double *__restr
     if (blockIdx.x == 0 && threadIdx.x == 0) pp[(int64_t)ch * S] = (FA0[(int64_t)ch * T] + yh[NL]) - z;
 }
 
-// deterministic final assembly: stats[ch] = [G0 | G1 | G2 | Xi' | s_all | s_m | s_y2 | 0]
+// deterministic final assembly: stats[ch] = [G0 | G1 | G2 | Xi' | s_all | s_m | s_y2 | 0].
+// G2 only enters the M-step through its sum over all ring states (sigma, baumwelch.jl:297-307), so the
+// real onsets' share sum_k G2(a,k) = sum_t' rho_a(t') W2(t') is kept in entry (a, 1) and the other
+// entries only hold the virtual onsets' terms.
 __global__ __launch_bounds__(64) void kw_stats_final(WaveGeom g, int rowsG, const double *__restrict__ partG,
                                                      const double *__restrict__ partS,
                                                      const double *__restrict__ extra, double *__restrict__ stats)
 {
     const int N = g.N, L = g.L, i = blockIdx.x, ch = blockIdx.y, lane = threadIdx.x;
-    const int NL = N * L, ws = 2 * N + 3, total = 3 * NL + N + 4;
+    const int NL = N * L, ws = 3 * N + 3, total = 3 * NL + N + 4;
     const double *pS = partS + (int64_t)ch * g.nch * ws;
-    const double *pG = partG + (int64_t)ch * rowsG * 2 * NL;
+    const double *pG = partG + (int64_t)ch * rowsG * NL;
     double acc = 0.0;
     if (i < NL) {
         const int a = i / L;
         for (int r = lane; r < g.nch; r += 64) acc += pS[(size_t)r * ws + N + a];
-    } else if (i < 3 * NL) {
+    } else if (i < 2 * NL) {
         const int e = i - NL;
-        for (int r = lane; r < rowsG; r += 64) acc += pG[(size_t)r * 2 * NL + e];
+        for (int r = lane; r < rowsG; r += 64) acc += pG[(size_t)r * NL + e];
+    } else if (i < 3 * NL) {
+        const int e = i - 2 * NL, a = e / L;
+        if (e % L == 0)
+            for (int r = lane; r < g.nch; r += 64) acc += pS[(size_t)r * ws + 2 * N + a];
     } else if (i < 3 * NL + N) {
         for (int r = lane; r < g.nch; r += 64) acc += pS[(size_t)r * ws + (i - 3 * NL)];
     } else if (i < 3 * NL + N + 3) {
-        for (int r = lane; r < g.nch; r += 64) acc += pS[(size_t)r * ws + 2 * N + (i - 3 * NL - N)];
+        for (int r = lane; r < g.nch; r += 64) acc += pS[(size_t)r * ws + 3 * N + (i - 3 * NL - N)];
     }
     acc = wave_sum(acc);
     if (lane == 0) stats[(int64_t)ch * total + i] = acc + (i < 3 * NL ? extra[(int64_t)ch * 3 * NL + i] : 0.0);
@@ -947,7 +974,7 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
                              r->FV, r->FREF, r->fpre, r->trash); }
         { WPROF(r, "kw_bwd", st);
           hipLaunchKernelGGL(kb, dim3(nchT), dim3(64), ldsb, st, g, r->d_cst, d_y, r->Rf, r->FA0, r->FV,
-                             r->FREF, r->fpre, r->rho, r->partS, r->Zc, r->bpre, r->bown, r->yhead, r->trash); }
+                             r->FREF, r->fpre, r->W2, r->rho, r->partS, r->Zc, r->bpre, r->bown, r->yhead, r->trash); }
         HS_HIP(hipGetLastError());
         // certificate + edge terms beside the statistics kernel
         HS_HIP(hipEventRecord(r->ev_a, st));
@@ -969,7 +996,7 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
             rowsG = (int)((g.T + kGxSubs * 8 * (int64_t)kGxBv - 1) / (kGxSubs * 8 * (int64_t)kGxBv));
             constexpr int RRx = kGxTR + HSx, RRPx = RRx + RRx / 16 + 1;
             const size_t l1 = ((size_t)8 * (RRPx * NPx + 2) + (size_t)8 * (kGxTR + 19 + LPTx * (ntx - 1))) * 8;
-            const size_t l2 = (size_t)4 * ntx * 2 * 4 * 64 * 8;
+            const size_t l2 = (size_t)4 * ntx * 4 * 64 * 8;
             const size_t lds = l1 > l2 ? l1 : l2;
             constexpr int NM = NN <= 8 ? NN : 8;
             auto go = [&](auto kern) -> int {

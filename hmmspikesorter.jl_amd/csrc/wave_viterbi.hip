@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64, wave_occ<N>()) void kw_vit(WaveGeom g, const Wa
                 *dst = pw[w];
             }
         }
-        D0 = wave_bcast(Dn, 63);  // idle lanes carry the identity, so lane 63 holds the last live value
+        D0 = wave_bcast(Dn, nact - 1);  // the last live lane
         rs += W; rs = rs >= RB ? rs - RB : rs;
         ws += W; ws = ws >= RB ? ws - RB : ws;
     };

@@ -113,7 +113,7 @@ def test_dpp_scans_match_shuffle_references(H):
     inp = np.concatenate([rng.normal(-1, 2, 64), rng.normal(0, 5, 64), rng.uniform(0.2, 1.0, 64),
                           rng.uniform(0, 2, 64)])
     inp[64 + 7] = -np.inf
-    out = np.zeros(704)
+    out = np.zeros(896)
     fn = H._lib.lib().hmmsort_selftest_scans
     fn.argtypes = [C.c_void_p, C.c_void_p]
     fn.restype = C.c_int
@@ -134,3 +134,6 @@ def test_dpp_scans_match_shuffle_references(H):
     assert np.array_equal(out[512:576], out[576:640])
     assert out[512] == 123.5 and np.array_equal(out[513:576], inp[:63])
     assert np.all(out[640:704] == inp[63])
+    # single-precision envelope scan (forward/backward scale) and float lane shift
+    assert np.allclose(out[704:768], a2, rtol=1e-5, atol=1e-4) and np.allclose(out[768:832][np.isfinite(b2)], b2[np.isfinite(b2)], rtol=1e-5, atol=1e-4)
+    assert out[832] == 7.25 and np.array_equal(out[833:896], inp[:63].astype(np.float32).astype(np.float64))
