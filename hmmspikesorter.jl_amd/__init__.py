@@ -12,6 +12,8 @@ from .api import (HMMSpikeTemplateModel, HMMSpikingModel, StateMatrix, backward,
                   predict, reconstruct_signal, train_model, train_step, unroll_mlseq, update,
                   viterbi)
 from .device import Plan
+from .postprocess import (condense_candidates, condense_templates, find_best_overlap, match_templates,
+                          prune_templates, remove_small, remove_sparse)
 from .sortdata import get_lp, sort_data
 from .synth import create_signal, create_spike_template
 
@@ -19,4 +21,6 @@ __all__ = ["StateMatrix", "HMMSpikeTemplateModel", "HMMSpikingModel", "forward",
            "update", "train_model", "train_step", "viterbi", "reconstruct_signal", "unroll_mlseq",
            "fit", "predict", "extract_spiketimes", "Plan", "create_signal", "create_spike_template", "HmmsortError",
            "set_option", "get_option", "device_count", "ENGINE_AUTO", "ENGINE_STRICT",
-           "ENGINE_RING", "ENGINE_BLOCKED", "ENGINE_WAVE", "get_lp", "sort_data"]
+           "ENGINE_RING", "ENGINE_BLOCKED", "ENGINE_WAVE", "get_lp", "sort_data", "find_best_overlap",
+           "condense_candidates", "condense_templates", "remove_sparse", "remove_small", "prune_templates",
+           "match_templates"]

@@ -40,6 +40,13 @@ class StateMatrix:
         return self.states.size == 0
 
     @staticmethod
+    def null():
+        """StateMatrix()  types.jl:12: the null model, a single noise state"""
+        tr = np.zeros(1, dtype=TRANS_DTYPE)
+        tr[0] = (1, 1, 0.0)
+        return StateMatrix(np.ones((1, 1), dtype=np.int16, order="F"), tr, np.array([1.0]), 0, 0, 1, False)
+
+    @staticmethod
     def create(N, K, lp, allow_overlaps=True, pp=None):
         """StateMatrix(N, K, lp[, pp], allow_overlaps=true)  types.jl:135-146."""
         L = lib()
@@ -238,7 +245,7 @@ class _EMSession:
         return lA_n, mu_n, float(o[K * N])
 
 
-def train_model(X, *args, callback=None, verbose=0, p0=None, rng=None, postprocess=None):
+def train_model(X, *args, callback=None, verbose=0, p0=None, rng=None, postprocess="reference"):
     """The three `train_model` methods of baumwelch.jl:
 
       train_model(X, state_matrix, mu0, sigma0)                  one EM step         :362-370
@@ -246,10 +253,11 @@ def train_model(X, *args, callback=None, verbose=0, p0=None, rng=None, postproce
       train_model(X, N=3, K=60, resolve_overlaps=False, nsteps=8[, callback])         :311-322
 
     The loop stays on the host exactly as in the reference (callback(mu) before every step, stop
-    when the state matrix becomes empty); each step is one GPU call.  The reference runs its
-    template merge/prune (condense_templates, remove_sparse, remove_small, baumwelch.jl:340-349:
-    outside the hot path) between the two rounds of steps; pass it as
-    `postprocess(state_matrix, mu, sigma) -> (state_matrix, mu)` to get the same schedule.
+    when the state matrix becomes empty); each step is one GPU call.  Between the two rounds of
+    steps the reference merges and prunes templates (condense_templates, remove_sparse, remove_small,
+    baumwelch.jl:340-349): `postprocess="reference"` (default) runs the restatement in postprocess.py,
+    `None` skips the stage, a callable `postprocess(state_matrix, mu, sigma) -> (state_matrix, mu)`
+    replaces it.
     """
     X = _signal(X)
     if len(args) >= 1 and isinstance(args[0], StateMatrix):
@@ -267,8 +275,13 @@ def train_model(X, *args, callback=None, verbose=0, p0=None, rng=None, postproce
                 state_matrix, mu, sigma = em.step(state_matrix, mu, sigma, verbose=verbose)
                 if state_matrix.isempty():
                     break
-            if postprocess is not None:
+            if postprocess == "reference":
+                from .postprocess import reference_postprocess
+                state_matrix, mu = reference_postprocess(state_matrix, mu, sigma, verbose=verbose)
+            elif postprocess is not None:
                 state_matrix, mu = postprocess(state_matrix, mu, sigma)
+            if state_matrix.N == 0:
+                return state_matrix, mu, sigma      # every template was pruned: the null model
             for _ in range(nsteps // 2):
                 state_matrix, mu, sigma = em.step(state_matrix, mu, sigma, verbose=verbose)
         finally:

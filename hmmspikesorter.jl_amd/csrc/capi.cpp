@@ -425,7 +425,8 @@ int hmmsort_plan_debug_array(hmmsort_plan *p, int which, double *out, int64_t n)
     HS_CHECK(p && out && p->wave, HMMSORT_EINVAL, "plan_debug_array: needs a wave plan");
     HS_HIP(hipDeviceSynchronize());
     const WaveDev *w = p->wave;
-    const double *src = which == 0 ? w->FA0 : which == 1 ? w->FREF : which == 2 ? w->FV : which == 3 ? w->rho : w->Rf;
+    const double *src = which == 0 ? w->FA0 : which == 1 ? w->FREF : which == 2 ? w->FV : which == 3 ? w->rho :
+                        which == 4 ? w->Rf : which == 5 ? w->vend : w->vpre;
     HS_HIP(hipMemcpy(out, src, n * sizeof(double), hipMemcpyDeviceToHost));
     return HMMSORT_OK;
 }

@@ -293,20 +293,39 @@ __global__ __launch_bounds__(64, wave_occ<N>()) void kw_vit(WaveGeom g, const Wa
 __global__ __launch_bounds__(64) void kw_vit_check(WaveGeom g, const double *__restrict__ vpre,
                                                    const double *__restrict__ vend,
                                                    int32_t *__restrict__ vfail, int64_t *__restrict__ diag,
-                                                   int final_round)
+                                                   int final_round, double *__restrict__ dbg)
 {
     const int lane = threadIdx.x;
     const int cg = blockIdx.x, c = cg % g.nch;
     if (c == 0) { if (lane == 0) vfail[cg] = 0; return; }
     const int64_t SR = 1 + (int64_t)g.N * g.L;
     double lo = INFINITY, hi = -INFINITY;
+    int64_t ilo = -1, ihi = -1, ibad = -1;
     bool bad = false;
     for (int64_t i = lane; i < SR; i += 64) {
         const double p = vpre[cg * SR + i], e = vend[(cg - 1) * SR + i];
-        if (p == e) { lo = fmin(lo, 0.0); hi = fmax(hi, 0.0); continue; }  // covers -inf vs -inf
+        if (p == e) {   // -inf on both sides (an unreachable entry) says nothing about the frame constant
+            if (fabs(p) < INFINITY) { lo = fmin(lo, 0.0); hi = fmax(hi, 0.0); }
+            continue;
+        }
         const double d = p - e;
-        if (!(fabs(d) < INFINITY)) { bad = true; continue; }                // NaN or one-sided infinity
-        lo = fmin(lo, d); hi = fmax(hi, d);
+        if (!(fabs(d) < INFINITY)) { bad = true; ibad = i; continue; }      // NaN or one-sided infinity
+        if (d < lo) { lo = d; ilo = i; }
+        if (d > hi) { hi = d; ihi = i; }
+    }
+    if (dbg && final_round) {   // debug record: the extreme entries of the first boundaries
+        for (int o = 32; o > 0; o >>= 1) {
+            const double l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+            const long long il2 = __shfl_xor((long long)ilo, o), ih2 = __shfl_xor((long long)ihi, o), ib2 = __shfl_xor((long long)ibad, o);
+            if (l2 < lo) { lo = l2; ilo = il2; }
+            if (h2 > hi) { hi = h2; ihi = ih2; }
+            if (ib2 > ibad) ibad = ib2;
+        }
+        if (lane == 0 && c <= 3) {
+            double *r = dbg + 16 + 8 * (c - 1);
+            r[0] = (double)cg; r[1] = lo; r[2] = (double)ilo; r[3] = hi; r[4] = (double)ihi; r[5] = (double)ibad;
+            r[6] = ilo >= 0 ? vpre[cg * SR + ilo] : 0.0; r[7] = ilo >= 0 ? vend[(cg - 1) * SR + ilo] : 0.0;
+        }
     }
     lo = -wave_max(-lo); hi = wave_max(hi);
     const bool anybad = __any(bad);
@@ -646,13 +665,13 @@ int wave_viterbi_post(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll,
         auto kern = r->uniform_cx ? kw_vit<N, true> : kw_vit<N, false>;
         for (int round = 0; round < kVitRounds && g.nch > 1; round++) {
             { WPROF(r, "kw_vit_check", st);
-              hipLaunchKernelGGL(kw_vit_check, dim3(nchT), dim3(64), 0, st, g, r->vpre, r->vend, r->vfail, r->diag, 0); }
+              hipLaunchKernelGGL(kw_vit_check, dim3(nchT), dim3(64), 0, st, g, r->vpre, r->vend, r->vfail, r->diag, 0, nullptr); }
             { WPROF(r, "kw_vit_redo", st);
               hipLaunchKernelGGL(kern, dim3(nchT), dim3(64), lds, st, g, r->d_cst, d_y, r->Rf, r->virt,
                                  r->ysum, r->psi, r->vpre, r->vend, r->vfail, (uint32_t *)r->trash, 1); }
         }
         { WPROF(r, "kw_vit_check", st);
-          hipLaunchKernelGGL(kw_vit_check, dim3(nchT), dim3(64), 0, st, g, r->vpre, r->vend, r->vfail, r->diag, 1); }
+          hipLaunchKernelGGL(kw_vit_check, dim3(nchT), dim3(64), 0, st, g, r->vpre, r->vend, r->vfail, r->diag, 1, r->dbg); }
         { WPROF(r, "kw_vit_tail", st);
           hipLaunchKernelGGL(kw_vit_tail, dim3(g.C), dim3(64), 0, st, g, r->d_cst, r->ysum, r->vend, r->final_state,
                              r->diag); }
