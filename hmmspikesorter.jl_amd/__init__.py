@@ -6,7 +6,7 @@ import it through the root-level shim:  `import hmmsort_amd`.
 """
 from . import _lib, dist, synth
 from ._lib import (ENGINE_AUTO, ENGINE_BLOCKED, ENGINE_RING, ENGINE_STRICT, ENGINE_WAVE, HmmsortError, device_count,
-                   get_option, set_option)
+                   get_option, set_option, shutdown)
 from .api import (HMMSpikeTemplateModel, HMMSpikingModel, StateMatrix, backward, extract_spiketimes,
                   fit, forward,
                   predict, reconstruct_signal, train_model, train_step, unroll_mlseq, update,
@@ -20,7 +20,7 @@ from .synth import create_signal, create_spike_template
 __all__ = ["StateMatrix", "HMMSpikeTemplateModel", "HMMSpikingModel", "forward", "backward",
            "update", "train_model", "train_step", "viterbi", "reconstruct_signal", "unroll_mlseq",
            "fit", "predict", "extract_spiketimes", "Plan", "create_signal", "create_spike_template", "HmmsortError",
-           "set_option", "get_option", "device_count", "ENGINE_AUTO", "ENGINE_STRICT",
+           "set_option", "get_option", "shutdown", "device_count", "ENGINE_AUTO", "ENGINE_STRICT",
            "ENGINE_RING", "ENGINE_BLOCKED", "ENGINE_WAVE", "get_lp", "sort_data", "find_best_overlap",
            "condense_candidates", "condense_templates", "remove_sparse", "remove_small", "prune_templates",
            "match_templates"]

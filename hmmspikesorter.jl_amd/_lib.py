@@ -130,6 +130,11 @@ def set_option(key, value):
     check(lib().hmmsort_set_option(key.encode(), int(value)))
 
 
+def shutdown():
+    """hmmsort_shutdown: free the idle plans and device buffers the host-buffer entry points keep"""
+    check(lib().hmmsort_shutdown())
+
+
 def get_option(key):
     v = C.c_int64(0)
     check(lib().hmmsort_get_option(key.encode(), C.byref(v)))

@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
+#include <mutex>
 
 #include "hmmsort_internal.h"
 #include "ring_common.h"
@@ -44,6 +46,82 @@ struct PlanGuard {
     ~PlanGuard() { if (p) hmmsort_plan_destroy(p); }
 };
 
+// ---- idle plans of the host-buffer entry points ---------------------------------------------
+// hmmsort_viterbi / hmmsort_em_step are what a reference-side binding calls once per EM iteration or per
+// channel: same T, same model shape, new numbers.  Creating the plan (workspace hipMalloc,
+// geometry) and the signal/output buffers costs more than the sweeps, so an entry point leaves its plan and
+// buffers here when it returns and the next call with the same key takes them and re-arms the plan with
+// hmmsort_plan_set_model.  A slot is owned by exactly one call while in use (taken OUT of the list), so
+// host threads never share a plan; the list itself is behind a mutex.  hmmsort_shutdown() empties it.
+struct HostSlot {
+    hmmsort_plan *plan = nullptr;
+    DevBuf dy, dx, dll, dstats, dout;
+    int64_t T = 0, engine_opt = 0, block = 0, halo = 0;
+    int device = 0;
+    ~HostSlot() { if (plan) hmmsort_plan_destroy(plan); }
+    void drop_plan()
+    {
+        if (plan) hmmsort_plan_destroy(plan);
+        plan = nullptr;
+    }
+};
+std::mutex g_slots_mu;
+std::vector<std::unique_ptr<HostSlot>> g_slots;  // idle, least recently used first
+
+void trim_slots(size_t keep)
+{
+    std::vector<std::unique_ptr<HostSlot>> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_slots_mu);
+        while (g_slots.size() > keep) {
+            dead.push_back(std::move(g_slots.front()));
+            g_slots.erase(g_slots.begin());
+        }
+    }
+    // hipFree outside the lock
+}
+
+std::unique_ptr<HostSlot> take_slot(int64_t T, const int16_t *states, int64_t N, int64_t K, int64_t S,
+                                    const Options &opt)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(g_slots_mu);
+    for (size_t i = g_slots.size(); i-- > 0;) {
+        HostSlot &h = *g_slots[i];
+        const HostModel &m = h.plan->model;
+        if (h.T != T || h.device != dev || h.engine_opt != opt.engine || h.block != opt.block ||
+            h.halo != opt.halo || m.N != N || m.K != K || m.S != S)
+            continue;
+        if (memcmp(m.states.data(), states, m.states.size() * sizeof(int16_t))) continue;
+        std::unique_ptr<HostSlot> out = std::move(g_slots[i]);
+        g_slots.erase(g_slots.begin() + i);
+        return out;
+    }
+    return nullptr;
+}
+
+void give_slot(std::unique_ptr<HostSlot> slot, const Options &opt)
+{
+    if (!slot || !slot->plan || opt.plan_cache <= 0) return;
+    {
+        std::lock_guard<std::mutex> lk(g_slots_mu);
+        g_slots.push_back(std::move(slot));
+    }
+    trim_slots((size_t)options_get().plan_cache);
+}
+
+std::unique_ptr<HostSlot> new_slot(int64_t T, const Options &opt)
+{
+    std::unique_ptr<HostSlot> h(new HostSlot());
+    h->T = T;
+    h->engine_opt = opt.engine;
+    h->block = opt.block;
+    h->halo = opt.halo;
+    if (hipGetDevice(&h->device) != hipSuccess) (void)hipGetLastError();
+    return h;
+}
+
 // two rings with bit-identical templates and entry probabilities: every decision between them is a
 // tie up to the rounding of the reference's own sums (near-ties)
 bool ring_has_twins(const HostModel &m)
@@ -83,6 +161,7 @@ int plan_create_engine(hmmsort_plan **out, int64_t T, const int16_t *states, int
     HS_CHECK(T >= 1, HMMSORT_EINVAL, "plan_create: T must be >= 1 (got %lld)", (long long)T);
     int rc = need_device();
     if (rc) return rc;
+    const Options opt = options_get();
     hmmsort_plan *p = new hmmsort_plan();
     PlanGuard guard{p};
     p->T = T;
@@ -103,18 +182,15 @@ int plan_create_engine(hmmsort_plan **out, int64_t T, const int16_t *states, int
     if ((engine_req == HMMSORT_ENGINE_AUTO || engine_req == HMMSORT_ENGINE_WAVE) && wave_ok) {
         p->engine = HMMSORT_ENGINE_WAVE;
         p->models.assign(1, p->model);
-        rc = wave_create(&p->wave, p->models, T, options().block,
-                         halo_req >= 0 ? halo_req : options().halo);
+        rc = wave_create(&p->wave, p->models, T, opt.block, halo_req >= 0 ? halo_req : opt.halo);
     } else if (want_ring && ring_ok) {
         p->engine = HMMSORT_ENGINE_RING;
-        rc = ring_create(&p->ring, p->model, T, options().block,
-                         halo_req >= 0 ? halo_req : options().halo);
+        rc = ring_create(&p->ring, p->model, T, opt.block, halo_req >= 0 ? halo_req : opt.halo);
     } else if (engine_req == HMMSORT_ENGINE_BLOCKED ||
                (engine_req == HMMSORT_ENGINE_AUTO && T >= blocked_min_samples())) {
         // overlap models and other lists the ring engine does not take: blocked sweep
         p->engine = HMMSORT_ENGINE_BLOCKED;
-        rc = generic_create(&p->gen, p->model, T, true, options().block,
-                            halo_req >= 0 ? halo_req : options().halo);
+        rc = generic_create(&p->gen, p->model, T, true, opt.block, halo_req >= 0 ? halo_req : opt.halo);
         if (rc == HMMSORT_EUNSUP && engine_req == HMMSORT_ENGINE_AUTO) {
             // a list the blocked sweep does not take (in-degree > 256): op-for-op single sweep
             p->engine = HMMSORT_ENGINE_STRICT;
@@ -159,18 +235,21 @@ int hmmsort_set_device(int device)
 int hmmsort_set_option(const char *key, int64_t value)
 {
     HS_CHECK(key, HMMSORT_EINVAL, "set_option: null key");
-    Options &o = options();
     if (!strcmp(key, "engine")) {
         HS_CHECK(value >= 0 && value <= 4, HMMSORT_EINVAL, "set_option: engine must be 0..4");
-        o.engine = value;
+        options_modify([&](Options &o) { o.engine = value; });
     } else if (!strcmp(key, "block")) {
         HS_CHECK(value >= 0, HMMSORT_EINVAL, "set_option: block must be >= 0");
-        o.block = value;
+        options_modify([&](Options &o) { o.block = value; });
     } else if (!strcmp(key, "halo")) {
         HS_CHECK(value >= 0, HMMSORT_EINVAL, "set_option: halo must be >= 0");
-        o.halo = value;
+        options_modify([&](Options &o) { o.halo = value; });
     } else if (!strcmp(key, "escalate")) {
-        o.escalate = value != 0;
+        options_modify([&](Options &o) { o.escalate = value != 0; });
+    } else if (!strcmp(key, "plan_cache")) {
+        HS_CHECK(value >= 0 && value <= 64, HMMSORT_EINVAL, "set_option: plan_cache must be 0..64");
+        options_modify([&](Options &o) { o.plan_cache = value; });
+        trim_slots((size_t)value);
     } else {
         set_error("set_option: unknown key '%s'", key);
         return HMMSORT_EINVAL;
@@ -181,12 +260,13 @@ int hmmsort_set_option(const char *key, int64_t value)
 int hmmsort_get_option(const char *key, int64_t *value)
 {
     HS_CHECK(key && value, HMMSORT_EINVAL, "get_option: null argument");
-    Options &o = options();
+    const Options o = options_get();
     if (!strcmp(key, "engine")) *value = o.engine;
     else if (!strcmp(key, "block")) *value = o.block;
     else if (!strcmp(key, "halo")) *value = o.halo;
     else if (!strcmp(key, "escalate")) *value = o.escalate;
-    else if (!strcmp(key, "last_escalations")) *value = o.last_escalations;
+    else if (!strcmp(key, "plan_cache")) *value = o.plan_cache;
+    else if (!strcmp(key, "last_escalations")) *value = last_escalations();
     else {
         set_error("get_option: unknown key '%s'", key);
         return HMMSORT_EINVAL;
@@ -194,7 +274,13 @@ int hmmsort_get_option(const char *key, int64_t *value)
     return HMMSORT_OK;
 }
 
-int hmmsort_shutdown(void) { return HMMSORT_OK; }
+// frees what the library keeps between calls: the idle plans and device buffers of the host-buffer
+// entry points (plans the caller created stay the caller's to destroy)
+int hmmsort_shutdown(void)
+{
+    trim_slots(0);
+    return HMMSORT_OK;
+}
 
 // ---- plan API ------------------------------------------------------------------------------
 
@@ -202,7 +288,7 @@ int hmmsort_plan_create(hmmsort_plan **plan_out, int64_t T, const int16_t *state
                         int64_t K, int64_t S, const hmm_trans *tr, int64_t R, const double *mu,
                         double sigma)
 {
-    return plan_create_engine(plan_out, T, states, N, K, S, tr, R, mu, sigma, options().engine);
+    return plan_create_engine(plan_out, T, states, N, K, S, tr, R, mu, sigma, options_get().engine);
 }
 
 // Batched plan: C recording channels of the same length and model SHAPE, each with its own transition
@@ -234,7 +320,8 @@ int hmmsort_plan_create_batched(hmmsort_plan **plan_out, int64_t C, int64_t T, c
         return HMMSORT_EUNSUP;
     }
     p->engine = HMMSORT_ENGINE_WAVE;
-    rc = wave_create(&p->wave, p->models, T, options().block, options().halo);
+    const Options opt = options_get();
+    rc = wave_create(&p->wave, p->models, T, opt.block, opt.halo);
     if (rc) return rc;
     guard.p = nullptr;
     *plan_out = p;
@@ -486,46 +573,59 @@ int hmmsort_viterbi(const double *y, int64_t T, const int16_t *states, int64_t N
 {
     HS_CHECK(y && x_out && ll_out, HMMSORT_EINVAL, "viterbi: null argument");
     HS_CHECK(T >= 1, HMMSORT_EINVAL, "viterbi: empty signal (T = %lld)", (long long)T);
-    DevBuf dy, dx, dll;
     int rc;
     if ((rc = need_device())) return rc;
-    if ((rc = dy.alloc(T * sizeof(double))) || (rc = dx.alloc(T * sizeof(int16_t))) ||
-        (rc = dll.alloc(sizeof(double))))
-        return rc;
-    HS_HIP(hipMemcpy(dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
-    options().last_escalations = 0;
-    int64_t halo = -1, engine = options().engine;
+    const Options opt = options_get();
+    last_escalations() = 0;
+    std::unique_ptr<HostSlot> slot = take_slot(T, states, N, K, S, opt);
+    if (!slot) slot = new_slot(T, opt);
+    HostSlot &h = *slot;
+    if (!h.dy.p && (rc = h.dy.alloc(T * sizeof(double)))) return rc;
+    if (!h.dx.p && (rc = h.dx.alloc(T * sizeof(int16_t)))) return rc;
+    if (!h.dll.p && (rc = h.dll.alloc(sizeof(double)))) return rc;
+    HS_HIP(hipMemcpy(h.dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
+    // an idle plan of the same shape: new numbers in, workspace kept.  A list it cannot take (a ring
+    // model that stopped being one) falls through to a fresh plan.
+    if (h.plan && hmmsort_plan_set_model(h.plan, tr, R, mu, sigma)) h.drop_plan();
+    bool keep = true;  // the plan is the one a first attempt with these options builds
+    int64_t halo = -1, engine = opt.engine;
     for (int attempt = 0;; attempt++) {
-        PlanGuard pg;
-        rc = plan_create_engine(&pg.p, T, states, N, K, S, tr, R, mu, sigma, engine, halo);
-        if (rc) return rc;
-        if (pg.p->ring && engine == HMMSORT_ENGINE_AUTO && ring_has_twins(pg.p->model)) {
+        if (!h.plan) {
+            rc = plan_create_engine(&h.plan, T, states, N, K, S, tr, R, mu, sigma, engine, halo);
+            if (rc) return rc;
+        }
+        if (h.plan->ring && engine == HMMSORT_ENGINE_AUTO && ring_has_twins(h.plan->model)) {
             // duplicate templates: which twin the reference decodes hangs on the last bit of its
             // own sums; only the op-for-op sweep reproduces that
             engine = HMMSORT_ENGINE_STRICT;
+            h.drop_plan();
+            keep = false;
             continue;
         }
-        rc = hmmsort_plan_viterbi(pg.p, dy.as<double>(), dx.as<int16_t>(), dll.as<double>(), nullptr);
+        rc = hmmsort_plan_viterbi(h.plan, h.dy.as<double>(), h.dx.as<int16_t>(), h.dll.as<double>(), nullptr);
         if (rc) return rc;
         HS_HIP(hipDeviceSynchronize());
-        if (pg.p->engine == HMMSORT_ENGINE_STRICT) break;
+        if (h.plan->engine == HMMSORT_ENGINE_STRICT) break;
         int64_t diag[8];
-        if ((rc = hmmsort_plan_diagnostics(pg.p, nullptr, diag))) return rc;
-        const bool ties = (pg.p->engine == HMMSORT_ENGINE_BLOCKED || pg.p->engine == HMMSORT_ENGINE_WAVE) &&
+        if ((rc = hmmsort_plan_diagnostics(h.plan, nullptr, diag))) return rc;
+        const bool ties = (h.plan->engine == HMMSORT_ENGINE_BLOCKED || h.plan->engine == HMMSORT_ENGINE_WAVE) &&
                           diag[7] != 0;
-        if ((diag[0] == 0 && !ties) || !options().escalate) break;
-        options().last_escalations = attempt + 1;
-        halo = next_halo(pg.p);
+        if ((diag[0] == 0 && !ties) || !opt.escalate) break;
+        last_escalations() = attempt + 1;
+        halo = next_halo(h.plan);
         if (attempt >= 3 || halo > T || ties) {
             // near-ties depend on the frame, not on the warm-up: straight to the op-for-op sweep
-            HS_CHECK(options().engine == HMMSORT_ENGINE_AUTO, HMMSORT_ENOCONV,
+            HS_CHECK(opt.engine == HMMSORT_ENGINE_AUTO, HMMSORT_ENOCONV,
                      "viterbi: %lld block boundaries fail the warm-up check, %lld blocks hold near-ties",
                      (long long)diag[0], (long long)diag[7]);
             engine = HMMSORT_ENGINE_STRICT;
         }
+        h.drop_plan();
+        keep = false;
     }
-    HS_HIP(hipMemcpy(x_out, dx.p, T * sizeof(int16_t), hipMemcpyDeviceToHost));
-    HS_HIP(hipMemcpy(ll_out, dll.p, sizeof(double), hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(x_out, h.dx.p, T * sizeof(int16_t), hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(ll_out, h.dll.p, sizeof(double), hipMemcpyDeviceToHost));
+    if (keep) give_slot(std::move(slot), opt);
     return HMMSORT_OK;
 }
 
@@ -620,53 +720,65 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
     HS_CHECK(T >= 2, HMMSORT_EINVAL, "em_step: need T >= 2");
     int rc;
     if ((rc = need_device())) return rc;
-    DevBuf dy;
-    if ((rc = dy.alloc(T * sizeof(double)))) return rc;
-    HS_HIP(hipMemcpy(dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
-    options().last_escalations = 0;
-    PlanGuard pg;
-    int64_t halo = -1, engine = options().engine;
+    const Options opt = options_get();
+    last_escalations() = 0;
+    std::unique_ptr<HostSlot> slot = take_slot(T, states, N, K, S, opt);
+    if (!slot) slot = new_slot(T, opt);
+    HostSlot &h = *slot;
+    if (!h.dy.p && (rc = h.dy.alloc(T * sizeof(double)))) return rc;
+    HS_HIP(hipMemcpy(h.dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
+    if (h.plan && hmmsort_plan_set_model(h.plan, tr, R, mu_inout, sigma)) h.drop_plan();
+    bool keep = true;
+    int64_t halo = -1, engine = opt.engine;
     for (int attempt = 0;; attempt++) {
-        if (pg.p) { hmmsort_plan_destroy(pg.p); pg.p = nullptr; }
-        rc = plan_create_engine(&pg.p, T, states, N, K, S, tr, R, mu_inout, sigma, engine, halo);
-        if (rc) return rc;
-        if (!pg.p->ring && !pg.p->wave) {
-            if (pg.p->engine == HMMSORT_ENGINE_STRICT) break;
+        if (!h.plan) {
+            rc = plan_create_engine(&h.plan, T, states, N, K, S, tr, R, mu_inout, sigma, engine, halo);
+            if (rc) return rc;
+        }
+        if (!h.plan->ring && !h.plan->wave) {
+            keep = false;
+            if (h.plan->engine == HMMSORT_ENGINE_STRICT) break;
             engine = HMMSORT_ENGINE_STRICT;  // materialised alpha/beta are the strict engine's job
+            h.drop_plan();
             continue;
         }
         const int64_t nlp = N;
-        DevBuf dstats, dout;
-        if ((rc = dstats.alloc(hmmsort_plan_stats_len(pg.p) * sizeof(double))) ||
-            (rc = dout.alloc((K * N + 1 + nlp + S) * sizeof(double))))
-            return rc;
-        if ((rc = hmmsort_plan_estep(pg.p, dy.as<double>(), dstats.as<double>(), nullptr))) return rc;
-        if ((rc = hmmsort_plan_mstep(pg.p, dstats.as<double>(), dout.as<double>(), nullptr))) return rc;
+        if (!h.dstats.p && (rc = h.dstats.alloc(hmmsort_plan_stats_len(h.plan) * sizeof(double)))) return rc;
+        if (!h.dout.p && (rc = h.dout.alloc((K * N + 1 + nlp + S) * sizeof(double)))) return rc;
+        if ((rc = hmmsort_plan_estep(h.plan, h.dy.as<double>(), h.dstats.as<double>(), nullptr))) return rc;
+        if ((rc = hmmsort_plan_mstep(h.plan, h.dstats.as<double>(), h.dout.as<double>(), nullptr))) return rc;
         HS_HIP(hipDeviceSynchronize());
         int64_t diag[8];
-        if ((rc = hmmsort_plan_diagnostics(pg.p, nullptr, diag))) return rc;
-        if ((diag[3] == 0 && diag[5] == 0) || !options().escalate)
-            return unpack_mstep(dout.as<double>(), K, N, S, nlp, mu_inout, sigma_out, lp_out, lp_cap,
-                                n_lp_out, pp_out);
-        options().last_escalations = attempt + 1;
-        halo = next_halo(pg.p);
+        if ((rc = hmmsort_plan_diagnostics(h.plan, nullptr, diag))) return rc;
+        if ((diag[3] == 0 && diag[5] == 0) || !opt.escalate) {
+            rc = unpack_mstep(h.dout.as<double>(), K, N, S, nlp, mu_inout, sigma_out, lp_out, lp_cap,
+                              n_lp_out, pp_out);
+            if (!rc && keep) give_slot(std::move(slot), opt);
+            return rc;
+        }
+        last_escalations() = attempt + 1;
+        halo = next_halo(h.plan);
         if (attempt >= 3 || halo > T) {
-            HS_CHECK(options().engine != HMMSORT_ENGINE_RING && options().engine != HMMSORT_ENGINE_WAVE,
+            HS_CHECK(opt.engine != HMMSORT_ENGINE_RING && opt.engine != HMMSORT_ENGINE_WAVE,
                      HMMSORT_ENOCONV, "em_step: %lld chain boundaries still fail the warm-up check",
                      (long long)(diag[3] + diag[5]));
             engine = HMMSORT_ENGINE_STRICT;
         }
+        // a wider warm-up changes the geometry: statistics buffer and plan are rebuilt
+        h.drop_plan();
+        if (h.dstats.p) { (void)hipFree(h.dstats.p); h.dstats.p = nullptr; }
+        keep = false;
     }
     // generic engine: forward -> backward -> update with materialised alpha/beta, all on device
-    const int64_t nlp = generic_n_lp(pg.p->gen);
+    const int64_t nlp = generic_n_lp(h.plan->gen);
     DevBuf da, db, dout;
     const size_t st = (size_t)S * T * sizeof(double);
     if ((rc = da.alloc(st)) || (rc = db.alloc(st)) ||
         (rc = dout.alloc((K * N + 1 + nlp + S) * sizeof(double))))
         return rc;
-    if ((rc = generic_forward(pg.p->gen, dy.as<double>(), da.as<double>(), nullptr))) return rc;
-    if ((rc = generic_backward(pg.p->gen, dy.as<double>(), db.as<double>(), nullptr))) return rc;
-    if ((rc = generic_update(pg.p->gen, da.as<double>(), db.as<double>(), dy.as<double>(),
+    if ((rc = generic_forward(h.plan->gen, h.dy.as<double>(), da.as<double>(), nullptr))) return rc;
+    if ((rc = generic_backward(h.plan->gen, h.dy.as<double>(), db.as<double>(), nullptr))) return rc;
+    if ((rc = generic_update(h.plan->gen, da.as<double>(), db.as<double>(), h.dy.as<double>(),
                              dout.as<double>(), nullptr)))
         return rc;
     HS_HIP(hipDeviceSynchronize());

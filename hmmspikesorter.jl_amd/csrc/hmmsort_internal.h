@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/hmmsort.h"
@@ -38,9 +39,12 @@ struct Options {
     int64_t block = 0;
     int64_t halo = 0;
     int64_t escalate = 1;          // host-buffer entry points retry with a doubled warm-up
-    int64_t last_escalations = 0;  // read-only: retries of the last host-buffer call
+    int64_t plan_cache = 4;        // idle plans (+ device buffers) the host-buffer entry points keep
 };
-Options &options();
+// process-wide options behind a mutex: entry points work on a snapshot taken when they start
+Options options_get();
+void options_modify(const std::function<void(Options &)> &f);
+int64_t &last_escalations();       // per host thread: retries of its last host-buffer call
 
 // ---- host-side model -----------------------------------------------------------------------
 // Ring structure of a no-overlap model (reference types.jl:94-113 with allow_overlaps=false):

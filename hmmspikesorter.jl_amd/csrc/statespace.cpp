@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstring>
 
+#include <mutex>
+
 #include "hmmsort_internal.h"
 
 namespace hmmsort {
@@ -22,10 +24,22 @@ void set_error(const char *fmt, ...)
 }
 const char *last_error() { return g_err; }
 
-Options &options()
+static std::mutex g_opt_mu;
+static Options g_opt;
+Options options_get()
 {
-    static Options o;
-    return o;
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    return g_opt;
+}
+void options_modify(const std::function<void(Options &)> &f)
+{
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    f(g_opt);
+}
+int64_t &last_escalations()
+{
+    static thread_local int64_t n = 0;
+    return n;
 }
 
 // number of states: types.jl:67-71

@@ -66,10 +66,20 @@ const char *hmmsort_last_error(void);
 int hmmsort_version(void);
 int hmmsort_device_count(int *count);
 int hmmsort_set_device(int device);
-/* keys: "engine" (above), "block" (ring engine time-block length, 0 = auto),
- *       "halo" (ring engine warm-up length, 0 = auto).  Process-wide defaults. */
+/* keys: "engine" (above), "block" (chain length in samples, 0 = auto), "halo" (warm-up length, 0 = auto),
+ *       "escalate" (host-buffer entry points retry with a wider warm-up / the strict engine when a
+ *       boundary certificate or the near-tie guard fires; default 1), "plan_cache" (idle plans the
+ *       host-buffer entry points keep between calls, default 4, 0 = none); read-only
+ *       "last_escalations" (retries of the calling thread's last host-buffer call).
+ * Process-wide defaults behind a mutex; an entry point works on the snapshot it takes when it starts,
+ * so options may be changed while other host threads are inside the library.  hmmsort_last_error is
+ * per thread. */
 int hmmsort_set_option(const char *key, int64_t value);
 int hmmsort_get_option(const char *key, int64_t *value);
+/* hmmsort_viterbi / hmmsort_em_step leave their plan, workspace and signal buffers in a small cache
+ * keyed by (device, T, state matrix, options) and re-arm it on the next call of the same shape (an EM
+ * loop, the channels of a recording).  hmmsort_shutdown frees that cache; plans made with
+ * hmmsort_plan_create stay the caller's. */
 int hmmsort_shutdown(void);
 
 /* ---- state space helpers (host side, no GPU needed) ------------------------------------ */

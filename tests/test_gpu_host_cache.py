@@ -1,0 +1,105 @@
+"""The host-buffer entry points (hmmsort_viterbi / hmmsort_em_step: what a reference-side binding calls,
+INTEGRATION.md) keep their plan and device buffers between calls: results must not depend on that, two host
+threads must be able to decode at once, and hmmsort_shutdown must give the memory back."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def model(H, N=4, K=60):
+    amps = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)][:N]
+    pp = [0.003, 0.001, 0.002, 0.0015][:N]
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, *a) for a in amps], 1))
+    return temps, pp, H.StateMatrix.create(N, K, np.log(pp), False)
+
+
+def test_cached_plan_gives_the_same_answers_as_a_fresh_one(H):
+    temps, pp, sm = model(H)
+    T = 300_000
+    ys = [H.create_signal(T, 0.3, pp, temps, seed=s) for s in (1, 2)]
+    mus = [temps, np.asfortranarray(temps * 0.9)]
+    H.set_option("plan_cache", 0)
+    ref = [(H.viterbi(y, sm, mu, sg), H.train_step(y, sm, mu.copy(order="F"), sg))
+           for y, mu, sg in zip(ys, mus, (0.3, 0.35))]
+    H.set_option("plan_cache", 4)
+    try:
+        for rep in range(2):               # second round runs on plans left by the first
+            for (y, mu, sg), ((x0, ll0), (sm0, mu0, s0)) in zip(zip(ys, mus, (0.3, 0.35)), ref):
+                x, ll = H.viterbi(y, sm, mu, sg)
+                assert np.array_equal(x, x0) and ll == ll0
+                sm1, mu1, s1 = H.train_step(y, sm, mu.copy(order="F"), sg)
+                assert np.array_equal(mu1, mu0) and s1 == s0
+                assert np.array_equal(sm1.transitions["lp"], sm0.transitions["lp"])
+    finally:
+        H.shutdown()
+
+
+def test_two_host_threads_decode_concurrently(H):
+    temps, pp, sm = model(H)
+    T = 2_000_000
+    ys = [H.create_signal(T, 0.3, pp, temps, seed=10 + i) for i in range(4)]
+    expect = [H.viterbi(y, sm, temps, 0.3) for y in ys]
+    out = [None] * 4
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = H.viterbi(ys[i], sm, temps, 0.3)
+                r = H.train_step(ys[i], sm, temps.copy(order="F"), 0.3)
+                assert np.isfinite(r[2])
+        except Exception as e:                  # noqa: BLE001 - reported below
+            errs.append(e)
+
+    # options are read and written while the workers run
+    stop = threading.Event()
+
+    def poke():
+        while not stop.is_set():
+            H.set_option("escalate", 1)
+            H.get_option("engine")
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    pk = threading.Thread(target=poke)
+    pk.start()
+    [t.start() for t in th]
+    [t.join() for t in th]
+    stop.set()
+    pk.join()
+    H.shutdown()
+    assert not errs, errs
+    for (x, ll), (x0, ll0) in zip(out, expect):
+        assert np.array_equal(x, x0) and ll == ll0
+
+
+def test_shutdown_frees_the_cached_buffers_and_em_step_is_cheap_when_cached(H):
+    import torch
+    temps, pp, sm = model(H)
+    T = 10_000_000
+    y = H.create_signal(T, 0.3, pp, temps, seed=5)
+    H.shutdown()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    H.train_step(y, sm, temps.copy(order="F"), 0.3)            # builds the plan
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 > T * 8                                # signal + workspace stay resident
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        H.train_step(y, sm, temps.copy(order="F"), 0.3)
+        ts.append(time.perf_counter() - t0)
+    H.set_option("plan_cache", 0)
+    t0 = time.perf_counter()
+    H.train_step(y, sm, temps.copy(order="F"), 0.3)
+    cold = time.perf_counter() - t0
+    H.set_option("plan_cache", 4)
+    print("hmmsort_em_step, 10 M samples from a pageable host buffer: cached %.2f ms, uncached %.2f ms"
+          % (1e3 * min(ts), 1e3 * cold))
+    assert min(ts) < cold
+    H.shutdown()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)
