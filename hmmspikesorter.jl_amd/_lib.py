@@ -41,6 +41,8 @@ SIGNATURES = {
     "hmmsort_generate_states": (_i64, [_i64, _i64, _int, _vp]),
     "hmmsort_build_transitions": (_i64, [_i64, _i64, _vp, _i64, _int, _vp, _i64]),
     "hmmsort_viterbi": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _f64, _vp, _vp]),
+    "hmmsort_viterbi_i16": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _f64, _vp, _vp]),
+    "hmmsort_samples_to_f64": (_int, [_vp, C.c_int, _i64, _i64, _vp, _vp]),
     "hmmsort_forward": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _f64, _vp]),
     "hmmsort_backward": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _f64, _vp]),
     "hmmsort_update": (_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _f64,

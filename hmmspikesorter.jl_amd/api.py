@@ -113,11 +113,14 @@ def _signal(y):
 
 def viterbi(y, lA, mu, sigma):
     """viterbi(y, lA::StateMatrix, mu, sigma) -> (x::Vector{Int16}, ll)   viterbi.jl:44-98."""
-    y = _signal(y)
+    raw = isinstance(y, np.ndarray) and y.dtype == np.int16 and y.ndim == 1
+    # int16 acquisition samples cross PCIe as they are and are widened in HBM (hmmsort.jl:84-88)
+    y = np.ascontiguousarray(y) if raw else _signal(y)
     keep, margs = _model_args(lA, mu, sigma)
     x = np.zeros(len(y), dtype=np.int16)
     ll = C.c_double(0.0)
-    check(lib().hmmsort_viterbi(ptr(y), len(y), *margs, ptr(x), C.cast(C.byref(ll), C.c_void_p)))
+    entry = lib().hmmsort_viterbi_i16 if raw else lib().hmmsort_viterbi
+    check(entry(ptr(y), len(y), *margs, ptr(x), C.cast(C.byref(ll), C.c_void_p)))
     return x, ll.value
 
 
@@ -337,7 +340,8 @@ def fit(templates, X, chunksize=None):
     stitch rule (leading non-silent samples of a chunk are skipped, trailing ones are handed to
     the next chunk, which restarts at the last silent sample).  The reference's call to the
     removed `gc()` (fit.jl:19) is not reproduced."""
-    X = _signal(X)
+    raw = isinstance(X, np.ndarray) and X.dtype == np.int16 and X.ndim == 1
+    X = np.ascontiguousarray(X) if raw else _signal(X)
     lA, mu, sigma = templates.state_matrix, templates.mu, templates.sigma
     if chunksize is None:
         x, ll = viterbi(X, lA, mu, sigma)
@@ -357,6 +361,12 @@ def fit(templates, X, chunksize=None):
     muf = np.asarray(mu, dtype=np.float64)
     twins = any(np.array_equal(muf[:, a], muf[:, b]) for a in range(lA.N) for b in range(a + 1, lA.N))
     dX = torch.from_numpy(X).cuda()
+    if raw:
+        # the acquisition's int16 samples: 2 bytes per sample over PCIe, widened in HBM (hmmsort.jl:84-88)
+        draw, dX = dX, torch.empty(n, dtype=torch.float64, device="cuda")
+        check(lib().hmmsort_samples_to_f64(draw.data_ptr(), 0, n, 1, dX.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream))
+        del draw
     dx = torch.zeros(min(chunksize, n), dtype=torch.int16, device="cuda")
     dll = torch.zeros(1, dtype=torch.float64, device="cuda")
     plans = {}

@@ -567,9 +567,9 @@ static int64_t next_halo(const hmmsort_plan *p)
     return h * 2;
 }
 
-int hmmsort_viterbi(const double *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
-                    int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
-                    int16_t *x_out, double *ll_out)
+static int viterbi_host(const void *y, int sample_type, int64_t T, const int16_t *states, int64_t N,
+                        int64_t K, int64_t S, const hmm_trans *tr, int64_t R, const double *mu,
+                        double sigma, int16_t *x_out, double *ll_out)
 {
     HS_CHECK(y && x_out && ll_out, HMMSORT_EINVAL, "viterbi: null argument");
     HS_CHECK(T >= 1, HMMSORT_EINVAL, "viterbi: empty signal (T = %lld)", (long long)T);
@@ -583,7 +583,14 @@ int hmmsort_viterbi(const double *y, int64_t T, const int16_t *states, int64_t N
     if (!h.dy.p && (rc = h.dy.alloc(T * sizeof(double)))) return rc;
     if (!h.dx.p && (rc = h.dx.alloc(T * sizeof(int16_t)))) return rc;
     if (!h.dll.p && (rc = h.dll.alloc(sizeof(double)))) return rc;
-    HS_HIP(hipMemcpy(h.dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
+    if (sample_type == HMMSORT_SAMPLES_F64) {
+        HS_HIP(hipMemcpy(h.dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        // raw samples: the decoded path's buffer has the size of an int16 signal and is free until the sweep
+        HS_CHECK(sample_type == HMMSORT_SAMPLES_I16, HMMSORT_EINVAL, "viterbi: unsupported sample type");
+        HS_HIP(hipMemcpy(h.dx.p, y, T * sizeof(int16_t), hipMemcpyHostToDevice));
+        if ((rc = dev_widen(h.dx.p, sample_type, T, 1, h.dy.as<double>(), nullptr))) return rc;
+    }
     // an idle plan of the same shape: new numbers in, workspace kept.  A list it cannot take (a ring
     // model that stopped being one) falls through to a fresh plan.
     if (h.plan && hmmsort_plan_set_model(h.plan, tr, R, mu, sigma)) h.drop_plan();
@@ -627,6 +634,30 @@ int hmmsort_viterbi(const double *y, int64_t T, const int16_t *states, int64_t N
     HS_HIP(hipMemcpy(ll_out, h.dll.p, sizeof(double), hipMemcpyDeviceToHost));
     if (keep) give_slot(std::move(slot), opt);
     return HMMSORT_OK;
+}
+
+int hmmsort_viterbi(const double *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
+                    int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
+                    int16_t *x_out, double *ll_out)
+{
+    return viterbi_host(y, HMMSORT_SAMPLES_F64, T, states, N, K, S, tr, R, mu, sigma, x_out, ll_out);
+}
+
+int hmmsort_viterbi_i16(const int16_t *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
+                        int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
+                        int16_t *x_out, double *ll_out)
+{
+    return viterbi_host(y, HMMSORT_SAMPLES_I16, T, states, N, K, S, tr, R, mu, sigma, x_out, ll_out);
+}
+
+int hmmsort_samples_to_f64(const void *d_in, int sample_type, int64_t T, int64_t stride, double *d_out,
+                           void *stream)
+{
+    HS_CHECK(T >= 0 && stride >= 1 && (T == 0 || (d_in && d_out)), HMMSORT_EINVAL,
+             "samples_to_f64: bad argument (T = %lld, stride = %lld)", (long long)T, (long long)stride);
+    int rc = need_device();
+    if (rc) return rc;
+    return dev_widen(d_in, sample_type, T, stride, d_out, (hipStream_t)stream);
 }
 
 static int fwd_bwd_host(bool fwd, const double *y, int64_t T, const int16_t *states, int64_t N,

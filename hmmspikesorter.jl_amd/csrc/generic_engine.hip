@@ -331,6 +331,41 @@ int dev_unroll(const int16_t *d_x, int64_t T, const int16_t *d_states, int64_t N
     return HMMSORT_OK;
 }
 
+// raw acquisition samples -> fp64 (the reference widens on the host, src/hmmsort.jl:84-88, and hands
+// 8 bytes per sample to fit; here 2-byte samples cross PCIe and are widened in HBM).  Every source type
+// converts exactly, so the result is the host conversion's bit for bit.
+template <typename Tin>
+__global__ void k_widen(const Tin *__restrict__ in, int64_t T, int64_t stride, double *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (double)in[i * stride];
+}
+
+int dev_widen(const void *d_in, int dtype, int64_t T, int64_t stride, double *d_out, hipStream_t st)
+{
+    if (T <= 0) return HMMSORT_OK;
+    const int blocks = (int)std::min<int64_t>((T + 255) / 256, 8192);
+    switch (dtype) {
+    case HMMSORT_SAMPLES_I16:
+        hipLaunchKernelGGL(k_widen<int16_t>, dim3(blocks), dim3(256), 0, st, (const int16_t *)d_in, T, stride, d_out);
+        break;
+    case HMMSORT_SAMPLES_I32:
+        hipLaunchKernelGGL(k_widen<int32_t>, dim3(blocks), dim3(256), 0, st, (const int32_t *)d_in, T, stride, d_out);
+        break;
+    case HMMSORT_SAMPLES_F32:
+        hipLaunchKernelGGL(k_widen<float>, dim3(blocks), dim3(256), 0, st, (const float *)d_in, T, stride, d_out);
+        break;
+    case HMMSORT_SAMPLES_F64:
+        hipLaunchKernelGGL(k_widen<double>, dim3(blocks), dim3(256), 0, st, (const double *)d_in, T, stride, d_out);
+        break;
+    default:
+        set_error("samples_to_f64: unknown sample type %d", dtype);
+        return HMMSORT_EINVAL;
+    }
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------

@@ -119,6 +119,7 @@ bool ring_supported(const HostModel &m, int64_t T, std::string *why);
 // misc device helpers (generic_engine.hip)
 int dev_reconstruct(const int16_t *d_x, int64_t T, const int16_t *d_states, int64_t N, int64_t S,
                     const double *d_mu, int64_t K, double *d_out, hipStream_t st);
+int dev_widen(const void *d_in, int dtype, int64_t T, int64_t stride, double *d_out, hipStream_t st);
 constexpr int kSpikeChunkHost = 4096;
 int dev_spike_compact(const int16_t *d_x, int64_t T, const uint32_t *d_match, int N, int S, int pass,
                       int64_t *d_cnt, const int64_t *d_offs, int64_t *d_times, int64_t cap,

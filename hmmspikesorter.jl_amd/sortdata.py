@@ -72,7 +72,8 @@ def sort_data(spike_forms, cinv, p, data, outputfile=None, dosave=True, max_temp
     data = np.asarray(data)
     if data.ndim == 2:
         data = data[:, 0]                                                      # view(data, :, 1) :80
-    dataf = np.ascontiguousarray(data, dtype=np.float64)                       # :84-88
+    # :84-88 converts to Float64 on the host; int16 samples are handed over as they are and widened in HBM
+    dataf = np.ascontiguousarray(data) if data.dtype == np.int16 else np.ascontiguousarray(data, dtype=np.float64)
     modelf = api.fit(templates, dataf, chunksize)                              # :90
     mlseq = api.unroll_mlseq(modelf.ml_seq, sm)                                # :92
     out = {"mlseq": mlseq, "ll": modelf.ll, "waveforms": templates.mu, "lp": lp, "sigma": sigma}

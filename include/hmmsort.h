@@ -103,6 +103,13 @@ int hmmsort_viterbi(const double *y, int64_t T, const int16_t *states, int64_t N
                     int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
                     int16_t *x_out, double *ll_out);
 
+/* The same decode from the acquisition's raw samples: the reference's CLI converts the int16 channel to
+ * Float64 on the host before fit (src/hmmsort.jl:79-88); here the 2-byte samples cross PCIe and are
+ * widened in HBM (exact, so the decode is the one hmmsort_viterbi gives on the converted signal). */
+int hmmsort_viterbi_i16(const int16_t *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
+                        int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
+                        int16_t *x_out, double *ll_out);
+
 /* forward(V, lA::StateMatrix, mu, sigma) -> alpha (S x T)            baumwelch.jl:25-51 */
 int hmmsort_forward(const double *y, int64_t T, const int16_t *states, int64_t N, int64_t K,
                     int64_t S, const hmm_trans *tr, int64_t R, const double *mu, double sigma,
@@ -246,6 +253,17 @@ int hmmsort_plan_unroll_mlseq(hmmsort_plan *plan, const int16_t *d_x, int16_t *d
  * hmmsort_extract_spiketimes; synchronises the stream. */
 int hmmsort_plan_extract_spiketimes(hmmsort_plan *plan, const int16_t *d_x, int64_t *times_out,
                                     int64_t cap, int64_t *counts_out, void *stream);
+
+/* Widening of raw samples already in device memory into the fp64 signal the plan calls take
+ * (src/hmmsort.jl:79-88: `view(data, :, 1)` of the acquisition array, converted to Float64): element i
+ * of the output is d_in[i * stride] (stride in elements: 1 for a channel stored contiguously, the
+ * channel count for sample-major recordings).  Exact for every source type.  Asynchronous on `stream`. */
+#define HMMSORT_SAMPLES_I16 0
+#define HMMSORT_SAMPLES_I32 1
+#define HMMSORT_SAMPLES_F32 2
+#define HMMSORT_SAMPLES_F64 3
+int hmmsort_samples_to_f64(const void *d_in, int sample_type, int64_t T, int64_t stride, double *d_out,
+                           void *stream);
 
 /* Per-kernel timing of the ring engine with HIP events recorded on the caller's stream (used by
  * bench.py for the roofline line).  hmmsort_plan_profile(plan, 1) switches bracketing on;

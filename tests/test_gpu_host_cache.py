@@ -103,3 +103,33 @@ def test_shutdown_frees_the_cached_buffers_and_em_step_is_cheap_when_cached(H):
     H.shutdown()
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)
+
+
+def test_int16_samples_are_widened_on_the_device(H):
+    # hmmsort.jl:79-88: column 1 of the acquisition array, converted to Float64, goes into fit
+    import torch
+    K = 24
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, 3.0, 0.8, 0.2),
+                                        H.create_spike_template(K, 4.0, 0.3, 0.2)], 1)) * 1000
+    pp = [0.004, 0.002]
+    sm = H.StateMatrix.create(2, K, np.log(pp), False)
+    T = 400_000
+    raw = np.round(H.create_signal(T, 300.0, pp, temps, seed=8)).astype(np.int16)
+    x0, ll0 = H.viterbi(raw.astype(np.float64), sm, temps, 300.0)
+    x1, ll1 = H.viterbi(raw, sm, temps, 300.0)                     # hmmsort_viterbi_i16
+    assert np.array_equal(x0, x1) and ll0 == ll1 and x0.max() > 1
+    tm = H.HMMSpikeTemplateModel(sm, temps, 300.0)
+    f0 = H.fit(tm, raw.astype(np.float64), 100_000)
+    f1 = H.fit(tm, raw, 100_000)
+    assert np.array_equal(f0.ml_seq, f1.ml_seq) and f0.ll == f1.ll
+    # a sample-major recording of 3 channels in device memory: channel 1 with stride 3
+    rec = np.stack([raw, raw[::-1], -raw], 1)
+    d_rec = torch.from_numpy(rec).cuda()
+    for dt, code in ((torch.int16, 0), (torch.int32, 1), (torch.float32, 2), (torch.float64, 3)):
+        src = d_rec.to(dt).contiguous()
+        out = torch.empty(T, dtype=torch.float64, device="cuda")
+        H._lib.check(H._lib.lib().hmmsort_samples_to_f64(src.data_ptr() + src.element_size(), code, T, 3,
+                                                          out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), rec[:, 1].astype(np.float64))
+    H.shutdown()
