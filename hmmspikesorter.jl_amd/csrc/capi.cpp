@@ -465,6 +465,7 @@ int hmmsort_plan_set_shard(hmmsort_plan *p, int64_t own_lo, int64_t own_hi, int 
 int64_t hmmsort_plan_stats_len(const hmmsort_plan *p)
 {
     if (p && p->wave) return wave_stats_len(p->wave);
+    if (p && p->gen && blocked_estep_supported(p->gen)) return blocked_stats_len(p->gen);
     if (!p || !p->ring) return 0;
     return ring_stats_len(p->ring);
 }
@@ -473,8 +474,9 @@ int hmmsort_plan_estep(hmmsort_plan *p, const double *d_y, double *d_stats, void
 {
     HS_CHECK(p && d_y && d_stats, HMMSORT_EINVAL, "plan_estep: null argument");
     if (p->wave) return wave_estep(p->wave, d_y, d_stats, (hipStream_t)stream);
+    if (p->gen && blocked_estep_supported(p->gen)) return blocked_estep(p->gen, d_y, d_stats, (hipStream_t)stream);
     HS_CHECK(p->ring, HMMSORT_EUNSUP,
-             "plan_estep: sufficient-statistics E-step needs the wave or ring engine (use hmmsort_em_step)");
+             "plan_estep: sufficient-statistics E-step needs the wave, ring or blocked engine (use hmmsort_em_step)");
     return ring_estep(p->ring, d_y, d_stats, (hipStream_t)stream);
 }
 
@@ -482,7 +484,8 @@ int hmmsort_plan_mstep(hmmsort_plan *p, const double *d_stats, double *d_out, vo
 {
     HS_CHECK(p && d_stats && d_out, HMMSORT_EINVAL, "plan_mstep: null argument");
     if (p->wave) return wave_mstep(p->wave, d_stats, d_out, (hipStream_t)stream);
-    HS_CHECK(p->ring, HMMSORT_EUNSUP, "plan_mstep: needs the wave or ring engine");
+    if (p->gen && blocked_estep_supported(p->gen)) return blocked_mstep(p->gen, d_stats, d_out, (hipStream_t)stream);
+    HS_CHECK(p->ring, HMMSORT_EUNSUP, "plan_mstep: needs the wave, ring or blocked engine");
     return ring_mstep(p->ring, d_stats, d_out, (hipStream_t)stream);
 }
 
@@ -766,14 +769,15 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
             rc = plan_create_engine(&h.plan, T, states, N, K, S, tr, R, mu_inout, sigma, engine, halo);
             if (rc) return rc;
         }
-        if (!h.plan->ring && !h.plan->wave) {
+        const bool blocked_es = h.plan->gen && blocked_estep_supported(h.plan->gen);
+        if (!h.plan->ring && !h.plan->wave && !blocked_es) {
             keep = false;
             if (h.plan->engine == HMMSORT_ENGINE_STRICT) break;
             engine = HMMSORT_ENGINE_STRICT;  // materialised alpha/beta are the strict engine's job
             h.drop_plan();
             continue;
         }
-        const int64_t nlp = N;
+        const int64_t nlp = blocked_es ? generic_n_lp(h.plan->gen) : N;
         if (!h.dstats.p && (rc = h.dstats.alloc(hmmsort_plan_stats_len(h.plan) * sizeof(double)))) return rc;
         if (!h.dout.p && (rc = h.dout.alloc((K * N + 1 + nlp + S) * sizeof(double)))) return rc;
         if ((rc = hmmsort_plan_estep(h.plan, h.dy.as<double>(), h.dstats.as<double>(), nullptr))) return rc;
@@ -790,7 +794,8 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
         last_escalations() = attempt + 1;
         halo = next_halo(h.plan);
         if (attempt >= 3 || halo > T) {
-            HS_CHECK(opt.engine != HMMSORT_ENGINE_RING && opt.engine != HMMSORT_ENGINE_WAVE,
+            HS_CHECK(opt.engine != HMMSORT_ENGINE_RING && opt.engine != HMMSORT_ENGINE_WAVE &&
+                         opt.engine != HMMSORT_ENGINE_BLOCKED,
                      HMMSORT_ENOCONV, "em_step: %lld chain boundaries still fail the warm-up check",
                      (long long)(diag[3] + diag[5]));
             engine = HMMSORT_ENGINE_STRICT;

@@ -33,6 +33,11 @@ struct GenericDev {
     int64_t *d_merged = nullptr;
     unsigned long long *d_bdiag = nullptr, *d_gapmin = nullptr;
     double *d_frame = nullptr;  // per block: frame constant relative to the previous block, |values|
+    // time-parallel E-step (generic_estep.hip), allocated on first use
+    double *d_es_win = nullptr, *d_es_rec = nullptr, *d_es_partG = nullptr, *d_es_partX = nullptr;
+    double *d_es_inw = nullptr, *d_es_outw = nullptr, *d_es_tmp = nullptr;
+    unsigned long long *d_es_diag = nullptr;
+    int es_grid = 0;
     int64_t upd_bytes = 0;
     int threads = 256;
     int64_t bytes = 0;
@@ -43,6 +48,12 @@ int blocked_set_model(GenericDev *g, const HostModel &m);
 void blocked_destroy(GenericDev *g);
 int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st);
 int blocked_diagnostics(GenericDev *g, hipStream_t st, int64_t diag[8]);
+bool blocked_estep_supported(const GenericDev *g);
+int64_t blocked_stats_len(const GenericDev *g);
+int blocked_estep(GenericDev *g, const double *d_y, double *d_stats, hipStream_t st);
+int blocked_mstep(GenericDev *g, const double *d_stats, double *d_out, hipStream_t st);
+int blocked_estep_diagnostics(GenericDev *g, hipStream_t st, int64_t diag[8]);
+void blocked_estep_destroy(GenericDev *g);
 void blocked_geometry(int64_t T, int64_t L, int64_t block_req, int64_t halo_req, int64_t *B,
                       int64_t *H, int64_t *nblk);
 

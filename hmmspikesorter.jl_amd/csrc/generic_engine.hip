@@ -441,6 +441,7 @@ void generic_destroy(GenericDev *g)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     blocked_destroy(g);
+    blocked_estep_destroy(g);
     delete g;
 }
 
@@ -458,7 +459,11 @@ void generic_geometry(const GenericDev *g, int64_t *block, int64_t *halo, int64_
 
 int generic_diagnostics(GenericDev *g, hipStream_t st, int64_t diag[8])
 {
-    if (g->blocked) return blocked_diagnostics(g, st, diag);
+    if (g->blocked) {
+        int rc = blocked_diagnostics(g, st, diag);
+        if (rc) return rc;
+        return blocked_estep_diagnostics(g, st, diag);
+    }
     return HMMSORT_OK;
 }
 

@@ -102,6 +102,12 @@ int generic_backward(GenericDev *g, const double *d_y, double *d_beta, hipStream
 int generic_update(GenericDev *g, const double *d_alpha, const double *d_beta, const double *d_y,
                    double *d_out, hipStream_t st);
 int64_t generic_n_lp(const GenericDev *g);
+// time-parallel E-step of the blocked generic engine (generic_estep.hip): sufficient statistics without
+// S x T arrays.  stats = [G0 (S) | G1 (S) | X (n_lp + 1) | Gamma0 | sum y^2]
+bool blocked_estep_supported(const GenericDev *g);
+int64_t blocked_stats_len(const GenericDev *g);
+int blocked_estep(GenericDev *g, const double *d_y, double *d_stats, hipStream_t st);
+int blocked_mstep(GenericDev *g, const double *d_stats, double *d_out, hipStream_t st);
 
 // ring (time-parallel) engine
 int ring_create(RingDev **r, const HostModel &m, int64_t T, int64_t block_req, int64_t halo_req);

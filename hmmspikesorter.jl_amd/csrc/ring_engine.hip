@@ -20,6 +20,8 @@ bool ring_supported(const HostModel &m, int64_t T, std::string *why)
     if (!m.ring.valid) return no("transition list is not the no-overlap ring pattern");
     if (m.ring.N > kRingMaxN) return no("more than 16 rings");
     if (m.ring.L < kRingMinL) return no("rings shorter than 16 states");
+    // k_halo_check keeps an L x 64 prefix table in LDS beside 8 KB of static arrays: 160 KB per workgroup
+    if ((int64_t)m.ring.L * 64 * 8 + 8192 > 160 * 1024) return no("rings longer than 304 states");
     if (T < 4 * (int64_t)m.ring.L || T < 512) return no("signal shorter than 4 ring lengths / 512 samples");
     return true;
 }

@@ -451,6 +451,7 @@ int ring_viterbi_post(RingDev *r, const double *d_y, int16_t *d_x, double *d_ll,
         PROF(r, "k_halo_check", st);
         hipLaunchKernelGGL(k_halo_check, dim3(g.ncol / 64), dim3(64 * kVChkParts), (size_t)g.L * 64 * sizeof(double), st,
                            g, ka, 1e-6, r->yT, r->Pv, r->D0pre, r->D0end, r->diag);
+        HS_HIP(hipGetLastError());  // a certificate that did not launch must not read as one that passed
     }
     { PROF(r, "k_transpose_x", st); hipLaunchKernelGGL(k_transpose_x, dim3(g.B / 64, g.ncol / 64), dim3(256), 0, st, r->xT, g.T,
                        g.B, g.ncol, d_x); }

@@ -104,7 +104,10 @@ class Plan:
         return int(lib().hmmsort_plan_stats_len(self._h))
 
     def mstep_len(self):
-        return self.K * self.N + 1 + self.N + self.S
+        """[mu (K x N) | sigma | xb[2:end] | pp (S)]: xb has one entry per transition leaving state 1
+        (baumwelch.jl:226), N + 1 of them without overlaps"""
+        nsrc1 = int((np.asarray(self.lA.transitions["src"]) == 1).sum())
+        return self.K * self.N + 1 + (nsrc1 - 1) + self.S
 
     def estep(self, d_y, d_stats, stream=0):
         check(lib().hmmsort_plan_estep(self._h, _dptr(d_y), _dptr(d_stats), C.c_void_p(stream)))
