@@ -109,7 +109,7 @@ __global__ __launch_bounds__(1024) void bes_block(BesArgs a)
         double *rec = a.rec + (size_t)blk * 6 * S;
         // ------------------------------------------------------------------ forward
         {
-            const int64_t t0 = blk == 0 ? 0 : lo - H;
+            const int64_t t0 = lo > H ? lo - H : 0;   // a warm-up reaching the start of the data is the exact sweep
             // column t0 = shifted emissions (baumwelch.jl:36 at the start of the data; a flat start elsewhere)
             const double y0 = a.y[t0];
             double pm = -INFINITY;

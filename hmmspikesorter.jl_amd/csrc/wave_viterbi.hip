@@ -390,8 +390,10 @@ __global__ __launch_bounds__(64) void kw_backtrace(WaveGeom g, const uint32_t *_
     constexpr int EB = wpsi_bits_c(N), EPW = wpsi_epw_c(N), PW = wpsi_words_c(N);
     constexpr int TS = PW <= 2 ? 64 : 32;   // samples per tile (static LDS stays below 64 KB)
     constexpr int RPI = 64 / TS;            // segment rows per load instruction
+    constexpr int XW = TS / 2;              // decoded ids leave as pairs (two int16 per word)
+    constexpr int XRI = 64 / XW;            // rows per store instruction
     __shared__ uint32_t tile[PW][64][TS + 1];
-    __shared__ int16_t xt[64][TS + 2];
+    __shared__ uint32_t xt[64][XW + 1];
     const int lane = threadIdx.x, ch = blockIdx.y;
     const int L = g.L, Bb = g.Bb, Hb = g.Hb;
     const int64_t T = g.T;
@@ -403,61 +405,125 @@ __global__ __launch_bounds__(64) void kw_backtrace(WaveGeom g, const uint32_t *_
     const int64_t planePsi = (int64_t)g.C * T;
     const uint32_t *pc = psi + (int64_t)ch * T;
     int16_t *xc = x + (int64_t)ch * T;
-    int a = -1, k = 0;
+    const bool xal = ((reinterpret_cast<uintptr_t>(xc)) & 3) == 0;   // odd T puts later channels on odd samples
+    // times relative to the segment start: u = t - s_lo
+    const int te_rel = active ? (int)(te - s_lo) : 0, hi_rel = (int)(s_hi - s_lo);
+    const int t1 = s_lo >= 1 ? 0 : 1;                      // the step at t = 0 has no predecessor
+    const int t2 = s_lo >= 2 ? 0 : (int)(2 - s_lo);        // psi(1) only decides x[0]: kw_first_state
+    // walk state: id = state id at the current sample, rem = steps left inside the ring (0 at a junction),
+    // (wi, sh) = word and bit offset of the psi entry the next junction decision reads (entry e = ring + 1)
+    int id = 1, rem = 0, wi = 0, sh = 0;
     if (active && te == T) {
         const int fs = final_state[ch];
-        if (fs > 0) { a = (fs - 1) / L; k = (fs - 1) % L + 1; }
+        if (fs > 0) {
+            const int a0 = (fs - 1) / L, k0 = (fs - 1) % L + 1, e0 = a0 + 1;
+            id = fs + 1; rem = k0 - 1; wi = e0 / EPW; sh = (e0 % EPW) * EB;
+        }
     }
-    int nflag = 0;
+    int nflag = 0, bs = 0;
     const int lr = lane / TS, lc = lane % TS;
-    for (int q = (Bb + Hb) / TS - 1; q >= 0; q--) {
-        // stage psi rows: row r = segment sg0 + r, samples s_lo(r) + TS q + lc
-#pragma unroll 4
-        for (int rr = 0; rr < 64; rr += RPI) {
-            const int r = rr + lr;
-            const int64_t t = (sg0 + r) * Bb + (int64_t)TS * q + lc;
-            const bool ok = (sg0 + r) < g.nseg && t < T;
+    constexpr bool ROWREG = PW <= 2;        // the lane's tile row in registers (wider rows stay in LDS)
+    uint32_t rowv[ROWREG ? PW : 1][ROWREG ? TS : 1], xr[XW];
+    // one tile of the walk, newest sample first.  FAST: every lane of the wave is inside its walk for the
+    // whole tile and (OWN) inside / (not OWN) behind its own segment, so no per-lane time predicates.
+    auto walk = [&](int q, auto fast_tag, auto own_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value, OWN = decltype(own_tag)::value;
 #pragma unroll
-            for (int w = 0; w < PW; w++) {
-                const uint32_t v = pc[w * planePsi + (ok ? t : 0)];
-                tile[w][r][lc] = ok ? v : 0u;
-            }
-        }
-        __syncthreads();
-#pragma unroll 4
         for (int i = TS - 1; i >= 0; i--) {
-            const int64_t t = s_lo + (int64_t)TS * q + i;
-            const bool live = active && t < te;
-            const int id = (a < 0) ? 1 : 2 + a * L + (k - 1);
-            if (live && t <= s_hi) {
-                if (t < s_hi) xt[lane][i] = (int16_t)id;
-                else bstate[(int64_t)ch * g.nseg + sg] = id;
+            const int u = TS * q + i;
+            const bool interior = rem > 0;
+            if (FAST ? OWN : true) {
+                if (i & 1) xr[i / 2] = (uint32_t)id << 16;
+                else xr[i / 2] |= (uint32_t)id & 0xffffu;
             }
-            const int e = a + 1;
-            uint32_t wsel = tile[0][lane][i];
+            uint32_t wsel;
+            if constexpr (ROWREG) {
+                wsel = rowv[0][i];
 #pragma unroll
-            for (int w = 1; w < PW; w++) wsel = (e / EPW == w) ? tile[w][lane][i] : wsel;
-            const uint32_t ent = (wsel >> ((e % EPW) * EB)) & ((1u << EB) - 1u);
-            const int p = (int)(ent & ((1u << (EB - 1)) - 1u));
-            const bool interior = (a >= 0) && (k > 1);
-            const bool step = live && t >= 1;
-            if (step && !interior && t < s_hi && t >= 2 && (ent >> (EB - 1))) nflag++;  // psi(1) only decides x[0]: kw_first_state
-            const int na = interior ? a : p - 1;
-            const int nk = interior ? k - 1 : (p == 0 ? 0 : L);
-            a = step ? na : a;
-            k = step ? nk : k;
+                for (int w = 1; w < PW; w++) wsel = (wi == w) ? rowv[w][i] : wsel;
+            } else {
+                wsel = tile[wi][lane][i];
+            }
+            const uint32_t ent = wsel >> sh;
+            const int pj = (int)(ent & ((1u << (EB - 1)) - 1u));
+            const int flag = (int)((ent >> (EB - 1)) & 1u);
+            // junction: predecessor p = 0 silent (id 1), else the last state of ring p-1 (id 1 + p L)
+            const int jid = 1 + pj * L, jrem = pj ? L - 1 : 0;
+            const int jwi = pj / EPW, jsh = (pj % EPW) * EB;
+            if (FAST) {
+                if (OWN) nflag += interior ? 0 : flag;
+                id = interior ? id - 1 : jid;
+                rem = interior ? rem - 1 : jrem;
+                wi = interior ? wi : jwi;
+                sh = interior ? sh : jsh;
+            } else {
+                const bool live = u < te_rel, step = live && u >= t1;
+                bs = (live && u == hi_rel) ? id : bs;
+                if (step && !interior && u < hi_rel && u >= t2) nflag += flag;
+                id = step ? (interior ? id - 1 : jid) : id;
+                rem = step ? (interior ? rem - 1 : jrem) : rem;
+                wi = step ? (interior ? wi : jwi) : wi;
+                sh = step ? (interior ? sh : jsh) : sh;
+            }
         }
-        __syncthreads();
-        if (TS * q < Bb) {  // owned rows: write x out, coalesced
-#pragma unroll 4
+    };
+    const int nq = (Bb + Hb) / TS;
+    for (int q = nq - 1; q >= 0; q--) {
+        // stage psi rows: row r = segment sg0 + r, samples s_lo(r) + TS q + lc.  Wave-uniform tile origin +
+        // 32-bit lane offsets; rows that do not exist read the origin and are staged as zeros.
+        {
+            const int64_t tb = sg0 * Bb + (int64_t)TS * q;
+            const uint32_t *base = pc + (tb < T ? tb : 0);
+#pragma unroll 16
             for (int rr = 0; rr < 64; rr += RPI) {
                 const int r = rr + lr;
-                const int64_t t = (sg0 + r) * Bb + (int64_t)TS * q + lc;
-                if ((sg0 + r) < g.nseg && t < T) xc[t] = xt[r][lc];
+                const bool ok = (sg0 + r) < g.nseg && tb + (int64_t)r * Bb + lc < T;
+                const uint32_t off = ok ? (uint32_t)(r * Bb + lc) : 0u;
+                uint32_t v[PW];
+#pragma unroll
+                for (int w = 0; w < PW; w++) v[w] = (base + w * planePsi)[off];
+#pragma unroll
+                for (int w = 0; w < PW; w++) tile[w][r][lc] = ok ? v[w] : 0u;
+            }
+        }
+        __syncthreads();
+        if constexpr (ROWREG) {
+#pragma unroll
+            for (int w = 0; w < PW; w++)
+#pragma unroll
+                for (int i = 0; i < TS; i++) rowv[w][i] = tile[w][lane][i];
+        }
+        const int u0 = TS * q, u1 = u0 + TS;
+        const bool own_tile = u0 < Bb;
+        // wave-uniform choice of the tile body
+        const bool lane_fast = u0 >= t1 && u1 <= te_rel &&
+                               (own_tile ? (u1 <= hi_rel && u0 >= t2) : (u0 > hi_rel));
+        const bool fast = __all(lane_fast);
+        if (fast && own_tile) walk(q, std::true_type(), std::true_type());
+        else if (fast) walk(q, std::true_type(), std::false_type());
+        else walk(q, std::false_type(), std::false_type());
+        if (own_tile) {  // owned rows: write x out, coalesced
+#pragma unroll
+            for (int j = 0; j < XW; j++) xt[lane][j] = xr[j];
+            __syncthreads();
+            const int xrw = lane / XW, xcw = lane % XW;
+#pragma unroll 8
+            for (int rr = 0; rr < 64; rr += XRI) {
+                const int r = rr + xrw;
+                const int64_t t = (sg0 + r) * Bb + (int64_t)TS * q + 2 * xcw;
+                if ((sg0 + r) < g.nseg && t < T) {
+                    const uint32_t v = xt[r][xcw];
+                    if (t + 1 < T && xal) *reinterpret_cast<uint32_t *>(xc + t) = v;
+                    else {
+                        xc[t] = (int16_t)(v & 0xffffu);
+                        if (t + 1 < T) xc[t + 1] = (int16_t)(v >> 16);
+                    }
+                }
             }
         }
         __syncthreads();
     }
+    if (active && hi_rel < te_rel) bstate[(int64_t)ch * g.nseg + sg] = bs;
     for (int o = 32; o > 0; o >>= 1) nflag += __shfl_xor(nflag, o);
     if (lane == 0 && nflag) atomicAdd((unsigned long long *)&diag[7], (unsigned long long)nflag);
 }

@@ -99,3 +99,17 @@ def test_blocked_plan_estep_mstep_and_short_warmup_escalates(O, H):
         H.set_option("halo", 0)
         H.set_option("engine", H.ENGINE_AUTO)
         H.shutdown()
+
+
+def test_blocks_shorter_than_the_warmup(O, H):
+    # a requested block of 128 samples under the default warm-up of 256: the warm-up of the first blocks
+    # reaches the start of the data (a fuzz case: the sweep started before sample 0)
+    y, sm, mu0 = overlap_case(H, 2, 12, 6_000, seed=21)
+    osm_n, omu, osig, olp, opp = O.train_step(y, to_oracle_sm(O, sm), mu0.copy(order="F"), 0.4)
+    H.set_option("block", 128)
+    try:
+        (sm_n, mu_n, sig_n), esc = step(H, H.ENGINE_BLOCKED, y, sm, mu0, 0.4)
+    finally:
+        H.set_option("block", 0)
+        H.shutdown()
+    assert np.allclose(mu_n, omu, rtol=1e-8, atol=1e-11) and abs(sig_n - osig) <= 1e-9 * osig
