@@ -728,12 +728,14 @@ __global__ __launch_bounds__(256) void kw_gsum_generic(WaveGeom g, const double 
 typedef double wg_d4 __attribute__((ext_vector_type(4)));
 constexpr int kGxTR = 64, kGxBv = 256, kGxSubs = 2;
 
+// blockIdx.z = lag group: NT accumulator tiles of LPT lags each, starting at lag z NT LPT (models with more
+// than 4 LPT lags sweep rho once per group).
 template <int N, int NT>
 __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__restrict__ y,
                                                   const double *__restrict__ rho, int nparts,
                                                   double *__restrict__ partG)
 {
-    constexpr int NP = N <= 1 ? 1 : (N <= 2 ? 2 : (N <= 4 ? 4 : 8));
+    constexpr int NP = N <= 1 ? 1 : (N <= 2 ? 2 : (N <= 4 ? 4 : (N <= 8 ? 8 : 16)));
     constexpr int NS = 16 / NP, LPT = 16 * NS, HS = 16 * (NS - 1);
     constexpr int TR = kGxTR, CW = 8, RR = TR + HS, Bv = kGxBv;
     constexpr int RRP = RR + RR / 16 + 1;          // padded rho rows per column
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__re
     constexpr int RRL = RR <= 64 ? 64 : (RR <= 128 ? 128 : (RR <= 256 ? 256 : 512)), YRL = (YR - 1) <= 128 ? 128 : ((YR - 1) <= 256 ? 256 : 512);
     constexpr int NRH = NP * RRL * CW / 256, NYM = CW * YRL / 256;
     extern __shared__ double lds[];
-    const int L = g.L, ch = blockIdx.y;
+    const int L = g.L, ch = blockIdx.y, lag0 = blockIdx.z * NT * LPT;
     const int64_t T = g.T;
     double *lr = lds;                              // [CW][RS]
     double *ly = lds + CW * RS;                    // [CW][YR]
@@ -776,7 +778,7 @@ __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__re
         for (int k = 0; k < NYM; k++) {
             const int i = tid + k * 256;
             const int rr = i % YRL, cc = i / YRL;
-            const int64_t t = (col0 + cc) * Bv + s0 + rr;
+            const int64_t t = (col0 + cc) * Bv + s0 + rr + lag0;
             const bool ok = rr < YR - 1 && t < T;
             const double v = yc[ok ? t : 0];
             ty_[k] = ok ? v : 0.0;
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__re
 #pragma unroll
         for (int w = 0; w < 4; w++) v += red[((w * NT + q) * 4 + r) * 64 + ln];
         const int j = ln & 15, a = j % NP, sft = j / NP;
-        const int lag = q * LPT + 16 * sft + (ln >> 4) + 4 * r;
+        const int lag = lag0 + q * LPT + 16 * sft + (ln >> 4) + 4 * r;
         if (a < N && lag < L) out[a * L + lag] = v;
     }
 }
@@ -988,26 +990,28 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
                                r->bpre, r->bown, r->rho, r->diag, r->dbg);
         }
         HS_HIP(hipEventRecord(r->ev_b, r->side));
-        constexpr int NPx = NN <= 1 ? 1 : (NN <= 2 ? 2 : (NN <= 4 ? 4 : 8));
+        constexpr int NPx = NN <= 1 ? 1 : (NN <= 2 ? 2 : (NN <= 4 ? 4 : (NN <= 8 ? 8 : 16)));
         constexpr int LPTx = 16 * (16 / NPx), HSx = LPTx - 16;
         const int ntx = (L + LPTx - 1) / LPTx;
         const bool generic = getenv("HMMSORT_GSUM_GENERIC") != nullptr;
-        if (!generic && NN <= 8 && ntx <= 4) {
+        if (!generic) {
+            // up to 4 accumulator tiles per workgroup; longer rings take one pass over rho per group of 4
+            const int ntk = NN > 8 ? 4 : (ntx < 4 ? ntx : 4), ngrp = (ntx + ntk - 1) / ntk;
             rowsG = (int)((g.T + kGxSubs * 8 * (int64_t)kGxBv - 1) / (kGxSubs * 8 * (int64_t)kGxBv));
             constexpr int RRx = kGxTR + HSx, RRPx = RRx + RRx / 16 + 1;
-            const size_t l1 = ((size_t)8 * (RRPx * NPx + 2) + (size_t)8 * (kGxTR + 19 + LPTx * (ntx - 1))) * 8;
-            const size_t l2 = (size_t)4 * ntx * 4 * 64 * 8;
+            const size_t l1 = ((size_t)8 * (RRPx * NPx + 2) + (size_t)8 * (kGxTR + 19 + LPTx * (ntk - 1))) * 8;
+            const size_t l2 = (size_t)4 * ntk * 4 * 64 * 8;
             const size_t lds = l1 > l2 ? l1 : l2;
-            constexpr int NM = NN <= 8 ? NN : 8;
             auto go = [&](auto kern) -> int {
                 int rc3 = wave_lds_attr2(kern, lds);
                 if (rc3) return rc3;
                 WPROF(r, "kw_gsum", st);
-                hipLaunchKernelGGL(kern, dim3(rowsG, g.C), dim3(256), lds, st, g, d_y, r->rho, rowsG, r->partG);
+                hipLaunchKernelGGL(kern, dim3(rowsG, g.C, ngrp), dim3(256), lds, st, g, d_y, r->rho, rowsG, r->partG);
                 return HMMSORT_OK;
             };
-            rc2 = ntx == 1 ? go(kw_gsum_mx<NM, 1>) : ntx == 2 ? go(kw_gsum_mx<NM, 2>)
-                : ntx == 3 ? go(kw_gsum_mx<NM, 3>) : go(kw_gsum_mx<NM, 4>);
+            if constexpr (NN > 8) rc2 = go(kw_gsum_mx<NN, 4>);
+            else rc2 = ntk == 1 ? go(kw_gsum_mx<NN, 1>) : ntk == 2 ? go(kw_gsum_mx<NN, 2>)
+                       : ntk == 3 ? go(kw_gsum_mx<NN, 3>) : go(kw_gsum_mx<NN, 4>);
             if (rc2) return rc2;
         } else {
             rowsG = r->gparts;
