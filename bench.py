@@ -47,10 +47,10 @@ def engine_bytes(kernel, N, T, info):
     warm = 1.0 + H / B                       # every chain re-reads its warm-up
     pw = {True: 1, False: 2}[N <= 4] if N <= 8 else 4
     per_sample = {
-        "kw_prepass": 8 + 8 * N,                         # y in, N ring-score planes out
+        "kw_prepass": 8 + 8 * N + 8,                     # y in, N ring-score planes + the window sums W2 out
         "kw_vit": (8 + 8 * N) * warm + 4 * pw,           # y + ring scores in, packed back-pointers out
         "kw_fwd": (8 + 8 * N) * warm + 8 * (N + 2),      # ... la0, fref, N onset masses out
-        "kw_bwd": (8 + 8 * N) * warm + 8 * (N + 2) + 8 * N,   # y, ring scores, forward outputs in; rho out
+        "kw_bwd": (8 + 8 * N) * warm + 8 + 8 * (N + 2) + 8 * N,   # y, ring scores, W2, forward outputs in; rho out
         "kw_gsum": 8 + 8 * N,                            # y, rho in
         "kw_backtrace": 4 * pw * 1.25 + 2,               # psi (with walk-in) in, x out
         "kw_ll_partial": 8 + 2,

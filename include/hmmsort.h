@@ -210,7 +210,9 @@ int hmmsort_plan_viterbi(hmmsort_plan *plan, const double *d_y, int16_t *d_x, do
 int hmmsort_plan_estep(hmmsort_plan *plan, const double *d_y, double *d_stats, void *stream);
 /* hmmsort_plan_viterbi + hmmsort_plan_estep of the same signal and model in one call: the three
  * serial sweeps (Viterbi, forward, backward) are independent and share one launch, so three times
- * as many wavefronts are resident.  Same results as the two separate calls.  Ring engine only. */
+ * as many wavefronts are resident (wave engine: the Viterbi sweep and its post-processing run on an
+ * internal stream beside the forward/backward sweeps).  Same results as the two separate calls.
+ * Wave and ring engines. */
 int hmmsort_plan_decode_estep(hmmsort_plan *plan, const double *d_y, int16_t *d_x, double *d_ll,
                               double *d_stats, void *stream);
 int64_t hmmsort_plan_stats_len(const hmmsort_plan *plan);
@@ -224,20 +226,30 @@ int64_t hmmsort_plan_stats_len(const hmmsort_plan *plan);
  * Default: the plan owns everything (one shard = the recording). */
 int hmmsort_plan_set_shard(hmmsort_plan *plan, int64_t own_lo, int64_t own_hi, int first, int last);
 /* M-step finish from (all-reduced) statistics, on device: d_out receives
- * [mu (K*N) | sigma (1) | lp_new (N) | pp (S)] = K*N + 1 + N + S doubles. */
+ * [mu (K*N) | sigma (1) | lp_new | pp (S)]; lp_new = xb[2:end] (baumwelch.jl:264) has one entry per
+ * transition leaving state 1 except the first: N entries for models without overlaps.  Blocked plans
+ * (overlap models) take the same three calls estep / all-reduce / mstep; their statistics vector is
+ * [G0 (S) | G1 (S) | X | Gamma0 | sum y^2]. */
 int hmmsort_plan_mstep(hmmsort_plan *plan, const double *d_stats, double *d_out, void *stream);
-/* diagnostics of the last ring-engine call on this plan (synchronises the stream):
+/* diagnostics of the last time-parallel call on this plan (synchronises the stream):
  * diag[0] = chain boundaries whose Viterbi warm-up missed the certificate (the warm-up's boundary
- *           scores must equal the previous chain's up to one constant, tolerance 1e-6),
- * diag[1] = backtrace stitch repairs, diag[2] = largest spread seen by that certificate (bit
+ *           scores must equal the previous chain's up to one constant; ring engine 1e-6 on the
+ *           relevant entries, wave engine 1e-9 on all 1 + N L entries).  The wave engine re-sweeps a
+ *           failing chain exactly from its predecessor's hand-off and counts only boundaries still
+ *           open after two such rounds,
+ * diag[1] = backtrace stitch repairs (wave engine: + chains re-swept exactly), diag[2] = largest spread seen by that certificate (bit
  *           pattern of a double), diag[3] / diag[5] = chain boundaries whose forward / backward warm-up
  *           missed the posterior-weighted tolerance 1e-9, diag[4] / diag[6] = the largest such
  *           error (IEEE-754 bit pattern of a double).  Viterbi calls fill [0..1], E-step calls
- *           [3..6].  Blocked engine: diag[0], diag[2] as above for its block boundaries, and
+ *           [3..6] (blocked plans: [3..6] from the certificates on gamma of generic_estep.hip).
+ *           Blocked engine: diag[0], diag[2] as above for its block boundaries, and
  *           diag[7] = blocks in which two candidates of a maximum came closer than the rounding
  *           granularity of the reference's trellis at that point (near-ties, e.g. duplicate
  *           templates): the blocks' additive frames may then break a tie the reference breaks by
- *           list order; hmmsort_viterbi re-decodes such signals with the strict engine. */
+ *           list order; hmmsort_viterbi re-decodes such signals with the strict engine.
+ *           Wave engine: diag[7] = junction decisions ON the decoded path whose margin is below
+ *           16 sqrt(L+2) ulp(|T1|max) + 4e-9 (the reference's own rounding noise at the magnitude its
+ *           trellis reaches on this signal); same consequence. */
 int hmmsort_plan_diagnostics(hmmsort_plan *plan, void *stream, int64_t diag[8]);
 
 /* reconstruct_signal (reconstruction.jl:1-10) and unroll_mlseq (extraction.jl:4-13) of a decoded
