@@ -75,6 +75,7 @@ struct WaveDev {
     // device model tables (per channel)
     WaveConst *d_cst = nullptr;       // C
     double *d_mean = nullptr;         // C x S
+    double *d_meanT = nullptr;        // C x L x N: ring means lag-major (the pre-pass loads a lag's N means as one wide scalar load)
     double *d_msq = nullptr;          // C x N*(L+1)
     double *d_cint = nullptr;         // C x N*(L+1)
     double *d_ctab = nullptr;         // C x (1 + 2N + N*N + N*L)

@@ -23,7 +23,9 @@ bool wave_supported(const HostModel &m, int64_t T, std::string *why)
     if (T < 4 * (int64_t)m.ring.L || T < 512) return no("signal shorter than 4 ring lengths / 512 samples");
     const int W = std::min(m.ring.L, 64);
     const int64_t RB = wround_up(m.ring.L + W, 32);
-    if (2 * (int64_t)m.ring.N * RB * 8 > kWaveLdsMax) return no("delay lines exceed the LDS of one CU");
+    // forward sweep: two delay lines per ring (one, in log form, above 8 rings); backward: N + 1 lines
+    const int64_t lines = m.ring.N > 8 ? m.ring.N + 1 : 2 * (int64_t)m.ring.N;
+    if (lines * (RB + 1) * 8 + 4096 > kWaveLdsMax) return no("delay lines exceed the LDS of one CU");
     return true;
 }
 
@@ -141,6 +143,13 @@ int wave_set_model(WaveDev *r, int ch, const HostModel &m)
     for (char u : r->ucx) r->uniform_cx = r->uniform_cx && u;
     HS_HIP(hipMemcpy(r->d_cst + ch, &k, sizeof(k), hipMemcpyHostToDevice));
     HS_HIP(hipMemcpy(r->d_mean + (size_t)ch * m.S, m.mean.data(), m.S * sizeof(double), hipMemcpyHostToDevice));
+    {
+        const int Nn = m.ring.N, Ll = m.ring.L;
+        std::vector<double> mt((size_t)Nn * Ll);
+        for (int a = 0; a < Nn; a++)
+            for (int k = 0; k < Ll; k++) mt[(size_t)k * Nn + a] = m.mean[1 + (size_t)a * Ll + k];
+        HS_HIP(hipMemcpy(r->d_meanT + (size_t)ch * Nn * Ll, mt.data(), mt.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     std::vector<double> cint((size_t)N * (L + 1), 0.0), msq((size_t)N * (L + 1), 0.0);
     for (int a = 0; a < N; a++) {
         double acc = 0.0, acc2 = 0.0;
@@ -190,6 +199,7 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
     auto A = [&](auto **p, int64_t n) { if (ok && wmalloc(p, n, &r->bytes)) ok = false; };
     A(&r->d_cst, C);
     A(&r->d_mean, C * m.S);
+    A(&r->d_meanT, C * N * L);
     A(&r->d_cint, C * N * (L + 1));
     A(&r->d_msq, C * N * (L + 1));
     A(&r->d_ctab, C * (1 + 2 * N + N * N + N * L));
@@ -273,7 +283,7 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
 void wave_destroy(WaveDev *r)
 {
     if (!r) return;
-    void *ptrs[] = {r->d_cst, r->d_mean, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->Rf, r->W2, r->virt, r->ysum,
+    void *ptrs[] = {r->d_cst, r->d_mean, r->d_meanT, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->Rf, r->W2, r->virt, r->ysum,
                     r->psi, r->vpre, r->vend, r->vfail, r->bstate, r->redo, r->final_state, r->part, r->FA0,
                     r->FV, r->FREF, r->fpre, r->bpre, r->bown, r->rho, r->Zc, r->partS, r->partG, r->yhead,
                     r->extra, r->pp, r->diag, r->dbg, r->trash};
@@ -325,10 +335,10 @@ __global__ __launch_bounds__(256) void kw_prepass(WaveGeom g, const WaveConst *_
     constexpr int R = pre_rows<N>(), TILE = 256 * R;
     extern __shared__ double ly[];  // y tile (TILE + L, padded); reused for the transposed results (TILE, padded)
     __shared__ double red[8];
-    const int ch = blockIdx.y, L = g.L, S = 1 + N * L, tid = threadIdx.x;
+    const int ch = blockIdx.y, L = g.L, tid = threadIdx.x;
     const int64_t T = g.T, t0 = (int64_t)blockIdx.x * TILE;
     const double *yc = y + (int64_t)ch * T;
-    const double *mc = mean + (int64_t)ch * S + 1;
+    const double *mc = mean + (int64_t)ch * N * L;    // lag-major: mc[k * N + a]
     auto pad = [](int i) { return i + i / R; };
     double s1 = 0.0, s2 = 0.0;
     for (int i = tid; i < TILE + L; i += 256) {
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(256) void kw_prepass(WaveGeom g, const WaveConst *_
     }
     double mv[N];
 #pragma unroll
-    for (int a = 0; a < N; a++) mv[a] = mc[a * L];
+    for (int a = 0; a < N; a++) mv[a] = mc[a];
     for (int k0 = 0; k0 < L; k0 += U) {
 #pragma unroll
         for (int kk = 0; kk < U; kk++) {
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(256) void kw_prepass(WaveGeom g, const WaveConst *_
                 const int kn = k + 1 < L ? k + 1 : k;
                 double mn[N];
 #pragma unroll
-                for (int a = 0; a < N; a++) mn[a] = mc[a * L + kn];   // wave-uniform (scalar loads)
+                for (int a = 0; a < N; a++) mn[a] = mc[kn * N + a];   // wave-uniform (one wide scalar load)
                 w[(kk + R) % U] = ly[pad(R * tid + k + R)];           // y[t + (k+1) + (R-1)]
 #pragma unroll
                 for (int r = 0; r < R; r++) {
@@ -461,7 +471,7 @@ int wave_prepare(WaveDev *r, const double *d_y, hipStream_t st)
         WPROF(r, "kw_prepass", st);
         constexpr int kPreTile = 256 * pre_rows<N>();
         hipLaunchKernelGGL((kw_prepass<N>), dim3((unsigned)((g.T + kPreTile - 1) / kPreTile), g.C), dim3(256),
-                           (size_t)((kPreTile + g.L) + (kPreTile + g.L) / pre_rows<N>() + 2) * sizeof(double), st, g, r->d_cst, d_y, r->d_mean, r->d_cint,
+                           (size_t)((kPreTile + g.L) + (kPreTile + g.L) / pre_rows<N>() + 2) * sizeof(double), st, g, r->d_cst, d_y, r->d_meanT, r->d_cint,
                            r->d_msq, r->Rf, r->W2, r->ysum);
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;

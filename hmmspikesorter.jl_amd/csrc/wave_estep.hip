@@ -70,7 +70,11 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
     constexpr int KSC = 5, KCP0 = 5 + N, KPEND = 5 + 2 * N, KCPX = 5 + 3 * N, KSIZE = 5 + 3 * N + N * N;
     extern __shared__ double lds[];
     const int L = g.L, W = g.W, RB = g.RB, B = g.B;
-    double *KC = lds, *DLv = lds + KSIZE, *DLs = lds + KSIZE + N * (RB + 1);  // onset t': (v_a, s_a), X_a = s_a + log v_a; row stride RB+1 (spare slot)
+    // onset t': (v_a, s_a), X_a = s_a + log v_a; row stride RB+1 (spare slot).  LOGDL (more than 8 rings: two lines
+    // per ring would leave one wave per CU at L = 255): ONE line per ring holding X_a itself -- one logarithm per
+    // ring and sample when the entry is stored, the exponential at the exit is the one the sweep takes anyway
+    constexpr bool LOGDL = N > 8;
+    double *KC = lds, *DLv = lds + KSIZE, *DLs = LOGDL ? DLv : lds + KSIZE + N * (RB + 1);
     const int lane = threadIdx.x;
     const int cg = blockIdx.x, ch = cg / g.nch, c = cg % g.nch;
     const int64_t T = g.T;
@@ -83,7 +87,8 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
     const int64_t FR = 1 + (int64_t)L * (N + 1);
     double *rec = fpre + cg * FR;
 
-    for (int i = lane; i < 2 * N * (RB + 1); i += 64) DLv[i] = 0.0;
+    if (LOGDL) for (int i = lane; i < N * (RB + 1); i += 64) DLv[i] = -INFINITY;
+    else for (int i = lane; i < 2 * N * (RB + 1); i += 64) DLv[i] = 0.0;
     {
         const WaveConst &Kg = cst[ch];
         if (lane == 0) { KC[0] = Kg.sc0; KC[1] = Kg.mean0; KC[2] = 1.0 / Kg.den; KC[3] = Kg.P00; KC[4] = fexp(-Kg.sc0); }
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
         for (int i = lane; i < N * L; i += 64) {
             const int a = i / L, j = i % L + 1;
             if (j < L) {
-                DLv[a * (RB + 1) + (L - j)] = 1.0;
+                if (!LOGDL) DLv[a * (RB + 1) + (L - j)] = 1.0;
                 DLs[a * (RB + 1) + (L - j)] = virt[((int64_t)ch * N + a) * (L + 1) + j];
             }
         }
@@ -109,8 +114,11 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
         x = fexp(q00 - M);
         if (lane < N) {
             const double f0 = fexp(-KC[KSC + lane]);
-            DLv[lane * (RB + 1) + L] = f0;
-            DLs[lane * (RB + 1) + L] = KC[KSC + lane] + Rc[(int64_t)lane * T];
+            if (LOGDL) DLs[lane * (RB + 1) + L] = Rc[(int64_t)lane * T];   // sc + R + log(exp(-sc))
+            else {
+                DLv[lane * (RB + 1) + L] = f0;
+                DLs[lane * (RB + 1) + L] = KC[KSC + lane] + Rc[(int64_t)lane * T];
+            }
             FVc[(int64_t)lane * T] = f0;
         }
         if (lane == 0) { FAc[0] = q00; FRc[0] = 0.0; }
@@ -146,9 +154,15 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
         double e = -INFINITY;
 #pragma unroll
         for (int a = 0; a < N; a++) {
-            v[a] = live ? DLv[a * (RB + 1) + rs] : 0.0;
-            E[a] = DLs[a * (RB + 1) + rs] + sc0;            // scale of the exit of ring a
-            e = fmax(e, scale_of(v[a], E[a]));
+            if (LOGDL) {
+                v[a] = 1.0;
+                E[a] = live ? DLs[a * (RB + 1) + rs] + sc0 : -INFINITY;   // log of the exit of ring a
+                e = fmax(e, E[a]);
+            } else {
+                v[a] = live ? DLv[a * (RB + 1) + rs] : 0.0;
+                E[a] = DLs[a * (RB + 1) + rs] + sc0;            // scale of the exit of ring a
+                e = fmax(e, scale_of(v[a], E[a]));
+            }
         }
         const double dd = d.y - KC[1];
         const double q0 = -((dd * dd) * KC[2]);           // KC[2] = 1/den: 1 ulp from the reference's division (bar here: 1e-6)
@@ -162,14 +176,14 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
         const double ref = Mt - q0;
         E[N] = (Mprev + sc0) - ref;
 #pragma unroll
-        for (int a = 0; a < N; a++) E[a] = v[a] > 0.0 ? fmin(E[a] - ref, 700.0) : -INFINITY;  // 0 * exp(big) = NaN
+        for (int a = 0; a < N; a++) E[a] = v[a] > 0.0 ? fmin(E[a] - ref, 700.0) : -INFINITY;  // 0 * exp(big) = NaN; -inf stays
         fexp_n<N + 1>(E);
         const double E0 = E[N];
         double Ea[N];
         double al = E0 * KC[3], be = 0.0;
 #pragma unroll
         for (int a = 0; a < N; a++) {
-            Ea[a] = v[a] * E[a];
+            Ea[a] = LOGDL ? E[a] : v[a] * E[a];
             be = __builtin_fma(Ea[a], KC[KPEND + a], be);
         }
         al = live ? al : 1.0;
@@ -199,10 +213,19 @@ __global__ __launch_bounds__(64, N <= 4 ? 3 : (N <= 8 ? 2 : 1)) void kw_fwd(Wave
             }
         }
         const int wsl = live ? ws : RB;   // idle lanes write the spare slot behind the ring
+        if (LOGDL) {
+            double lu[N];
 #pragma unroll
-        for (int a = 0; a < N; a++) {
-            DLv[a * (RB + 1) + wsl] = u[a];
-            DLs[a * (RB + 1) + wsl] = (ref + KC[KSC + a]) + d.R[a];
+            for (int a = 0; a < N; a++) lu[a] = u[a];
+            flog_n<N>(lu);
+#pragma unroll
+            for (int a = 0; a < N; a++) DLs[a * (RB + 1) + wsl] = ((ref + KC[KSC + a]) + d.R[a]) + (u[a] > 0.0 ? lu[a] : -INFINITY);
+        } else {
+#pragma unroll
+            for (int a = 0; a < N; a++) {
+                DLv[a * (RB + 1) + wsl] = u[a];
+                DLs[a * (RB + 1) + wsl] = (ref + KC[KSC + a]) + d.R[a];
+            }
         }
         if (MODE == 1) {
             const double la0 = Mt + flog(xt);
@@ -965,7 +988,7 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
     int rowsG = 0;
     int rc = dispatch_N(N, [&](auto n) {
         constexpr int NN = decltype(n)::value;
-        const size_t ldsf = ((size_t)2 * NN * (g.RB + 1) + 5 + 3 * NN + NN * NN) * sizeof(double);
+        const size_t ldsf = ((size_t)(NN > 8 ? 1 : 2) * NN * (g.RB + 1) + 5 + 3 * NN + NN * NN) * sizeof(double);
         const size_t ldsb = ((size_t)(NN + 1) * (g.RB + 1) + 4 + 3 * NN + NN * NN) * sizeof(double);
         auto kf = r->uniform_cx ? kw_fwd<NN, true> : kw_fwd<NN, false>;
         auto kb = r->uniform_cx ? kw_bwd<NN, true> : kw_bwd<NN, false>;
