@@ -557,6 +557,65 @@ __global__ void kw_stitch_check(WaveGeom g, const int16_t *__restrict__ x, const
     }
 }
 
+// Parallel repair of the queued segments whose successor is not queued itself (the common case: isolated
+// disagreements on busy signals with long rings).  One workgroup per segment: its psi goes global -> LDS in
+// full rows, lane 0 walks it from the successor's first state, all lanes write x.  A repaired segment whose
+// own first sample changed is caught by the second kw_stitch_check and the serial kw_stitch_fix below, which
+// also takes the chains of consecutive failures this kernel leaves alone.
+__global__ __launch_bounds__(64) void kw_stitch_fix_par(WaveGeom g, const uint32_t *__restrict__ psi,
+                                                        int16_t *__restrict__ x, int32_t *__restrict__ bstate,
+                                                        const int32_t *__restrict__ redo, int64_t *__restrict__ diag)
+{
+    extern __shared__ uint32_t shp[];                 // [PW][Bb + 1] psi of the segment and the sample after it | Bb ids
+    const int lane = threadIdx.x, n = redo[0];
+    const int L = g.L, Bb = g.Bb, PW = g.PW;
+    int16_t *xs = reinterpret_cast<int16_t *>(shp + (size_t)PW * (Bb + 1));
+    const int64_t planePsi = (int64_t)g.C * g.T;
+    for (int q = blockIdx.x; q < n; q += gridDim.x) {
+        const int32_t id = redo[1 + q];
+        const int ch = (int)(id / g.nseg);
+        const int64_t sg = id % g.nseg;
+        bool succ = false;
+        for (int j = lane; j < n; j += 64) succ = succ || (redo[1 + j] == id + 1 && sg + 1 < g.nseg);
+        if (__any(succ)) continue;
+        const uint32_t *pc = psi + (int64_t)ch * g.T;
+        int16_t *xc = x + (int64_t)ch * g.T;
+        const int64_t lo = sg * Bb, tn = lo + Bb;     // tn = first sample of segment sg + 1 (< T: sg is not the last)
+        const int want = xc[tn];
+        if (bstate[(int64_t)ch * g.nseg + sg] == want) continue;
+        for (int w = 0; w < PW; w++)
+            for (int i = lane; i <= Bb; i += 64) shp[w * (Bb + 1) + i] = pc[w * planePsi + lo + i];
+        __syncthreads();
+        if (lane == 0) {
+            int a = -1, k = 0;
+            int64_t nflag = 0;
+            if (want > 1) { a = (want - 2) / L; k = (want - 2) % L + 1; }
+            auto step = [&](int i) {                  // the move from sample lo + i to lo + i - 1
+                if (a >= 0 && k > 1) { k--; return; }
+                const int e = a + 1;
+                const uint32_t wv = shp[(e / g.epw) * (Bb + 1) + i];
+                const uint32_t ent = (wv >> ((e % g.epw) * g.EB)) & ((1u << g.EB) - 1u);
+                const int p = (int)(ent & ((1u << (g.EB - 1)) - 1u));
+                if (lo + i >= 2) nflag += ent >> (g.EB - 1);
+                if (p == 0) { a = -1; k = 0; }
+                else { a = p - 1; k = L; }
+            };
+            step(Bb);
+            for (int i = Bb - 1; i >= 0; i--) {
+                xs[i] = (int16_t)((a < 0) ? 1 : 2 + a * L + (k - 1));
+                if (lo + i == 0) break;
+                if (i > 0) step(i);
+            }
+            bstate[(int64_t)ch * g.nseg + sg] = want;
+            atomicAdd((unsigned long long *)&diag[1], 1ull);
+            if (nflag) atomicAdd((unsigned long long *)&diag[7], (unsigned long long)nflag);
+        }
+        __syncthreads();
+        for (int i = lane; i < Bb; i += 64) xc[lo + i] = xs[i];
+        __syncthreads();
+    }
+}
+
 __global__ void kw_stitch_fix(WaveGeom g, const uint32_t *__restrict__ psi, int16_t *__restrict__ x,
                               int32_t *__restrict__ bstate, const int32_t *__restrict__ redo,
                               int64_t *__restrict__ diag)
@@ -754,6 +813,13 @@ int wave_viterbi_post(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll,
       hipLaunchKernelGGL(kw_stitch_check, dim3((unsigned)((nsegT + 255) / 256)), dim3(256), 0, st, g, d_x, r->bstate,
                          r->redo); }
     { WPROF(r, "kw_stitch_fix", st);
+      // isolated failures in parallel, then a second check and the serial repair for what is left (chains of
+      // consecutive failures, first samples that changed)
+      const size_t ldsp = ((size_t)g.PW * (g.Bb + 1)) * sizeof(uint32_t) + (size_t)g.Bb * sizeof(int16_t) + 8;
+      hipLaunchKernelGGL(kw_stitch_fix_par, dim3(256), dim3(64), ldsp, st, g, r->psi, d_x, r->bstate, r->redo, r->diag);
+      HS_HIP(hipMemsetAsync(r->redo, 0, sizeof(int32_t), st));
+      hipLaunchKernelGGL(kw_stitch_check, dim3((unsigned)((nsegT + 255) / 256)), dim3(256), 0, st, g, d_x, r->bstate,
+                         r->redo);
       hipLaunchKernelGGL(kw_stitch_fix, dim3(1), dim3(64), 0, st, g, r->psi, d_x, r->bstate, r->redo, r->diag); }
     { WPROF(r, "kw_first_state", st);
       hipLaunchKernelGGL(kw_first_state, dim3(g.C), dim3(64), 0, st, g, r->d_cst, d_y, r->d_mean, r->d_ctab, d_x); }

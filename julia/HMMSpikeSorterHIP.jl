@@ -30,6 +30,18 @@ function viterbi(y::AbstractArray{Float64,1}, lA::StateMatrix, μ::Array{Float64
     x, ll[]
 end
 
+# the acquisition's Int16 samples (hmmsort.jl:79-88 converts them to Float64 on the host first): 2 bytes per
+# sample cross PCIe and are widened in HBM; same decode as on the converted signal
+function viterbi(y::AbstractArray{Int16,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64)
+    yv = y isa Array ? y : collect(y)
+    x = zeros(Int16, length(yv)); ll = Ref{Float64}(0.0)
+    check(ccall((:hmmsort_viterbi_i16, lib), Cint,
+        (Ptr{Int16}, Int64, Ptr{Int16}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Float64,
+         Ptr{Int16}, Ref{Float64}),
+        yv, length(yv), lA.states, lA.N, lA.K, lA.nstates, lA.transitions, length(lA.transitions), μ, σ, x, ll))
+    x, ll[]
+end
+
 function _fb(sym, V, lA, μ, σ)
     a = Array{Float64,2}(undef, lA.nstates, length(V))
     check(ccall((sym, lib), Cint,
@@ -57,7 +69,10 @@ function update(α::Array{Float64,2}, β::Array{Float64,2}, lA::StateMatrix, μ:
     _finish(lA, μ, σnew, lp, nlp, pp)
 end
 
-# one EM step, baumwelch.jl:362-370: a single call, alpha/beta never leave the GPU
+# one EM step, baumwelch.jl:362-370: a single call, alpha/beta never leave the GPU.  The library keeps the
+# plan (workspace, signal buffer) of the previous call of the same shape and re-arms it, so the EM loop of
+# baumwelch.jl:324-354 pays the PCIe copy of X and the sweeps per step, not a plan build (2.7 ms per step at
+# 10 M samples; `shutdown()` frees the cache).  Host threads may call concurrently.
 function train_model(X::Array{Float64,1}, state_matrix::StateMatrix, μ0::Array{Float64,2}, σ0::Float64; verbose=0)
     σnew = Ref{Float64}(0.0); nlp = Ref{Int64}(0)
     lp = zeros(length(state_matrix.transitions)); pp = zeros(state_matrix.nstates)
@@ -78,16 +93,22 @@ function reconstruct_signal(x::Array{T,1}, lA::StateMatrix, μ::Array{Float64,2}
     Y2
 end
 
+"Free the plans and device buffers the library keeps between host-buffer calls."
+shutdown() = check(ccall((:hmmsort_shutdown, lib), Cint, ()))
+set_option(key::String, value::Integer) = check(ccall((:hmmsort_set_option, lib), Cint, (Cstring, Int64), key, value))
+
 "Replace the reference's method bodies by the GPU versions (same signatures)."
 function enable!()
     @eval HMMSpikeSorter begin
         viterbi(y::AbstractArray{Float64,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64) = $(viterbi)(y, lA, μ, σ)
+        viterbi(y::AbstractArray{Int16,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64) = $(viterbi)(y, lA, μ, σ)
         forward(V::Array{Float64,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64) = $(forward)(V, lA, μ, σ)
         backward(V::Array{Float64,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64) = $(backward)(V, lA, μ, σ)
         update(α::Array{Float64,2}, β::Array{Float64,2}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64, x::Array{Float64,1}) = $(update)(α, β, lA, μ, σ, x)
         train_model(X::Array{Float64,1}, sm::StateMatrix, μ0::Array{Float64,2}, σ0::Float64; verbose=0) = $(train_model)(X, sm, μ0, σ0; verbose=verbose)
         reconstruct_signal(x::Array{T,1}, lA::StateMatrix, μ::Array{Float64,2}, σ::Float64) where T <: Integer = $(reconstruct_signal)(x, lA, μ, σ)
     end
+    atexit(shutdown)
     nothing
 end
 
