@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256) void kw_gsum_generic(WaveGeom g, const double 
 // rows go global -> registers -> LDS; the next tile's global loads are in flight during the MFMAs.
 // LDS rows of rho are padded by one row per 16 (the 4 delayed copies would otherwise hit one bank).
 typedef double wg_d4 __attribute__((ext_vector_type(4)));
-constexpr int kGxTR = 64, kGxBv = 256, kGxSubs = 2;
+constexpr int kGxTR = 64, kGxBv = 512, kGxSubs = 1;
 
 // blockIdx.z = lag group: NT accumulator tiles of LPT lags each, starting at lag z NT LPT (models with more
 // than 4 LPT lags sweep rho once per group).
