@@ -66,7 +66,7 @@ struct WaveDev {
     std::vector<char> ucx;            // per channel
     const double *bound_y = nullptr;
     hipStream_t side = nullptr, side2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
     std::vector<ProfEntry> prof;
     int64_t S = 0, K = 0;
     std::vector<RingModel> ring;      // per channel

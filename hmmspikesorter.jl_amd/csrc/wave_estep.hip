@@ -1007,12 +1007,13 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
         { WPROF(r, "kw_edges", r->side);
           hipLaunchKernelGGL(kw_edges, dim3((NL + 63) / 64, g.C), dim3(64), 0, r->side, g, d_y, r->Rf, r->virt, r->FA0,
                              r->rho, r->Zc, r->yhead, r->extra, r->pp); }
+        HS_HIP(hipEventRecord(r->ev_b, r->side));   // the final assembly waits for the edge terms only ...
         if (g.nch > 1) {
             WPROF(r, "kw_fb_check", r->side);
             hipLaunchKernelGGL(kw_fb_check, dim3(nchT), dim3(64), 0, r->side, g, 1e-9, r->FA0, r->FV, r->FREF, r->fpre,
                                r->bpre, r->bown, r->rho, r->diag, r->dbg);
         }
-        HS_HIP(hipEventRecord(r->ev_b, r->side));
+        HS_HIP(hipEventRecord(r->ev_c, r->side));   // ... the certificate only has to be done when the call's work is
         constexpr int NPx = NN <= 1 ? 1 : (NN <= 2 ? 2 : (NN <= 4 ? 4 : (NN <= 8 ? 8 : 16)));
         constexpr int LPTx = 16 * (16 / NPx), HSx = LPTx - 16;
         const int ntx = (L + LPTx - 1) / LPTx;
@@ -1051,6 +1052,7 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
     { WPROF(r, "kw_stats_final", st);
       hipLaunchKernelGGL(kw_stats_final, dim3(total, g.C), dim3(64), 0, st, g, rowsG, r->partG, r->partS, r->extra,
                          d_stats); }
+    HS_HIP(hipStreamWaitEvent(st, r->ev_c, 0));
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }
@@ -1080,10 +1082,12 @@ int wave_decode_estep(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll,
     if ((rc = wave_prepare(r, d_y, st))) return rc;
     HS_HIP(hipEventRecord(r->ev_fork, st));
     HS_HIP(hipStreamWaitEvent(r->side2, r->ev_fork, 0));
+    // the E-step chain is the critical path: its launches are enqueued first (the dozen small launches of the
+    // decode would otherwise hold the forward sweep back by their host-side enqueue time, ~0.1 ms)
+    if ((rc = wave_estep_sweeps(r, d_y, d_stats, st))) return rc;
     if ((rc = wave_viterbi_sweep(r, d_y, r->side2))) return rc;
     if ((rc = wave_viterbi_post(r, d_y, d_x, d_ll, r->side2))) return rc;
     HS_HIP(hipEventRecord(r->ev_join, r->side2));
-    if ((rc = wave_estep_sweeps(r, d_y, d_stats, st))) return rc;
     HS_HIP(hipStreamWaitEvent(st, r->ev_join, 0));
     return HMMSORT_OK;
 }
