@@ -121,6 +121,9 @@ def viterbi(y, lA, mu, sigma):
     ll = C.c_double(0.0)
     entry = lib().hmmsort_viterbi_i16 if raw else lib().hmmsort_viterbi
     check(entry(ptr(y), len(y), *margs, ptr(x), C.cast(C.byref(ll), C.c_void_p)))
+    if _lib.get_option("last_escalations") < 0:
+        import warnings
+        warnings.warn(_lib.last_error())      # near-ties the strict sweep could not re-decide (table too large)
     return x, ll.value
 
 

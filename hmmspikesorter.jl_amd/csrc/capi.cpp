@@ -246,6 +246,9 @@ int hmmsort_set_option(const char *key, int64_t value)
         options_modify([&](Options &o) { o.halo = value; });
     } else if (!strcmp(key, "escalate")) {
         options_modify([&](Options &o) { o.escalate = value != 0; });
+    } else if (!strcmp(key, "strict_limit_mb")) {
+        HS_CHECK(value >= 0, HMMSORT_EINVAL, "set_option: strict_limit_mb must be >= 0");
+        options_modify([&](Options &o) { o.strict_limit_mb = value; });
     } else if (!strcmp(key, "plan_cache")) {
         HS_CHECK(value >= 0 && value <= 64, HMMSORT_EINVAL, "set_option: plan_cache must be 0..64");
         options_modify([&](Options &o) { o.plan_cache = value; });
@@ -266,6 +269,7 @@ int hmmsort_get_option(const char *key, int64_t *value)
     else if (!strcmp(key, "halo")) *value = o.halo;
     else if (!strcmp(key, "escalate")) *value = o.escalate;
     else if (!strcmp(key, "plan_cache")) *value = o.plan_cache;
+    else if (!strcmp(key, "strict_limit_mb")) *value = o.strict_limit_mb;
     else if (!strcmp(key, "last_escalations")) *value = last_escalations();
     else {
         set_error("get_option: unknown key '%s'", key);
@@ -621,6 +625,24 @@ static int viterbi_host(const void *y, int sample_type, int64_t T, const int16_t
         const bool ties = (h.plan->engine == HMMSORT_ENGINE_BLOCKED || h.plan->engine == HMMSORT_ENGINE_WAVE) &&
                           diag[7] != 0;
         if ((diag[0] == 0 && !ties) || !opt.escalate) break;
+        if (ties && diag[0] == 0 && opt.engine == HMMSORT_ENGINE_AUTO) {
+            // The op-for-op sweep keeps S x T back-pointers (viterbi.jl:53; 0.8 TB at 4081 states x 10^8 samples:
+            // the reference itself decodes such recordings in chunks, fit.jl:11-42).  When that table cannot be
+            // had, the time-parallel path stands: it differs from the reference's at most at the flagged
+            // decisions, whose margins are inside the reference's own rounding noise.  last_escalations < 0
+            // = minus the number of such decisions.
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+            const double need = (double)S * (double)T * 2.0 + 16.0 * (double)T;
+            const double limit = opt.strict_limit_mb > 0 ? (double)opt.strict_limit_mb * 1048576.0 : 0.9 * (double)free_b;
+            if (need > limit) {
+                last_escalations() = -diag[7];
+                set_error("viterbi: %lld near-tie decisions on the decoded path; the strict sweep needs %.1f GB of "
+                          "back-pointers (limit %.1f GB): time-parallel path returned", (long long)diag[7], need / 1e9,
+                          limit / 1e9);
+                break;
+            }
+        }
         last_escalations() = attempt + 1;
         halo = next_halo(h.plan);
         if (attempt >= 3 || halo > T || ties) {

@@ -40,6 +40,7 @@ struct Options {
     int64_t halo = 0;
     int64_t escalate = 1;          // host-buffer entry points retry with a doubled warm-up
     int64_t plan_cache = 4;        // idle plans (+ device buffers) the host-buffer entry points keep
+    int64_t strict_limit_mb = 0;   // largest back-pointer table the strict fallback may allocate (0 = what is free)
 };
 // process-wide options behind a mutex: entry points work on a snapshot taken when they start
 Options options_get();

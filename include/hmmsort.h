@@ -69,8 +69,12 @@ int hmmsort_set_device(int device);
 /* keys: "engine" (above), "block" (chain length in samples, 0 = auto), "halo" (warm-up length, 0 = auto),
  *       "escalate" (host-buffer entry points retry with a wider warm-up / the strict engine when a
  *       boundary certificate or the near-tie guard fires; default 1), "plan_cache" (idle plans the
- *       host-buffer entry points keep between calls, default 4, 0 = none); read-only
- *       "last_escalations" (retries of the calling thread's last host-buffer call).
+ *       host-buffer entry points keep between calls, default 4, 0 = none), "strict_limit_mb" (largest
+ *       back-pointer table the strict fallback of hmmsort_viterbi may allocate, 0 = what is free); read-only
+ *       "last_escalations" (retries of the calling thread's last host-buffer call; NEGATIVE = minus the
+ *       number of near-tie decisions on a time-parallel path that was returned because the strict sweep's
+ *       S x T back-pointers do not fit: the path can differ from the reference's at those decisions only,
+ *       whose margins are inside the reference's own rounding noise; hmmsort_last_error has the text).
  * Process-wide defaults behind a mutex; an entry point works on the snapshot it takes when it starts,
  * so options may be changed while other host threads are inside the library.  hmmsort_last_error is
  * per thread. */
