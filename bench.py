@@ -243,6 +243,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- per-kernel timing (HIP events on the launch stream; separate, untimed pass) ----
+    # Runs BEFORE the warm-up steps: the first ~15 ms of work on an idle GPU run below its sustained clocks
+    # (10 timed steps after 3 warm-up steps: 1.25 ms/step, after 30: 1.18 ms/step), and this pass is untimed anyway.
+    # decode and E-step as two calls here: in the timed step their kernels overlap on two streams, which
+    # stretches every kernel's event-to-event time; run one after the other the durations are each kernel's own
+    step()                      # loads every kernel's code object before anything is measured
+    plan.viterbi(dy, dx, dll, stream)
+    plan.estep(dy, stats, stream)
+    fence()
+    nprof = max(1, min(args.steps, 8))
+    plan.profile(True)
+    for _ in range(nprof):
+        plan.bind(dy, stream)
+        plan.viterbi(dy, dx, dll, stream)
+        plan.estep(dy, stats, stream)
+        plan.mstep(stats, out, stream)
+        plan.unbind()
+    prof = plan.profile_read(stream)
+    plan.profile(False)
+
     for _ in range(args.warmup):
         step()
     fence()
@@ -262,20 +282,7 @@ def main():
     dE = plan.diagnostics(stream)
     diag = diag[:3] + dE[3:7] + diag[7:8]
 
-    # ---- per-kernel timing (HIP events on the launch stream; separate, untimed pass) ----
-    # decode and E-step as two calls here: in the timed step their kernels overlap on two streams, which
-    # stretches every kernel's event-to-event time; run one after the other the durations are each kernel's own
-    plan.profile(True)
-    for _ in range(max(1, min(args.steps, 5))):
-        plan.bind(dy, stream)
-        plan.viterbi(dy, dx, dll, stream)
-        plan.estep(dy, stats, stream)
-        plan.mstep(stats, out, stream)
-        plan.unbind()
-    prof = plan.profile_read(stream)
-    plan.profile(False)
     ksum = {k: v[0] / v[1] for k, v in prof.items()}           # average ms per launch
-    nprof = max(1, min(args.steps, 5))
     per_step_ms = {k: v[0] / nprof for k, v in prof.items()}   # ms per step (a kernel may launch more than once)
     dom = max(ksum, key=ksum.get)
     step_ms_kernels = sum(per_step_ms.values())
