@@ -101,6 +101,10 @@ def prune_templates(state_matrix, idx, resolve_overlaps=True):
     """prune_templates(state_matrix, idx, resolve_overlaps)   types.jl:161-166 (idx: 0-based template numbers)"""
     from .api import StateMatrix
     from .sortdata import get_lp
+    if len(idx) == 0:
+        # StateMatrix(0, K, Float64[]): no template left.  The reference builds a 0 x 1 state table (isempty);
+        # here that is the null model (types.jl:12), which train_model returns as it is
+        return StateMatrix.null()
     lp, tidx = get_lp(state_matrix)                              # tidx: 1-based neuron numbers
     tset = set(int(t) - 1 for t in tidx)
     pos = [p for p, v in enumerate(idx) if v in tset]            # findall(in(tidx), idx): POSITIONS in idx

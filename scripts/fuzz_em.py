@@ -36,7 +36,7 @@ for case in range(n_cases):
     sm = H.StateMatrix.create(N, K, lp, False)
     tag = "case %d: N=%d K=%d T=%d %s" % (case, N, K, T, "random start" if random_start else "perturbed")
     try:
-        sm_n, mu_n, sig_n = H.train_model(y, sm, mu.copy(order="F"), s0, 2)
+        sm_n, mu_n, sig_n = H.train_model(y, sm, mu.copy(order="F"), s0, 2, postprocess=None)   # the plain loop: 2 + 1 steps
         osm, omu, osig = to_oracle_sm(O, sm), mu.copy(order="F"), s0
         for _ in range(3):
             osm, omu, osig, _, _ = O.train_step(y, osm, omu, osig)

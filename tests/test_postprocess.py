@@ -52,3 +52,17 @@ def test_condense_prune_pipeline(H):
     kept = mu2[:, [idx[i] for i in idx2]]
     assert kept.shape[1] == sm4.N and kept.shape[1] >= 2
     assert np.all((kept ** 2).sum(0) > 1.0)       # only templates with real energy survive
+
+
+def test_every_template_pruned_gives_the_null_model(H):
+    # remove_small on templates that are all indistinguishable from noise: StateMatrix(0, K, Float64[]) in the
+    # reference (a 0 x 1 state table); here the null model, and train_model hands it back
+    K, N = 20, 3
+    sm = H.StateMatrix.create(N, K, np.log(np.full(N, 0.01)), False)
+    mu = np.zeros((K, N), order="F")
+    mu[1:, :] = 1e-3
+    sm2, idx = H.remove_small(sm, mu, 0.5)
+    assert idx == [] and sm2.N == 0 and sm2.nstates == 1
+    from hmmsort_amd.postprocess import reference_postprocess
+    sm3, mu3 = reference_postprocess(sm, mu, 0.5)
+    assert sm3.N == 0 and mu3.shape == (K, 0)
