@@ -46,11 +46,12 @@ def engine_bytes(kernel, N, T, info):
     B, H = max(1, info["block"]), info["halo"]
     warm = 1.0 + H / B                       # every chain re-reads its warm-up
     pw = {True: 1, False: 2}[N <= 4] if N <= 8 else 4
+    fused = N in (3, 4) and info.get("ring_len", 0) <= 64   # the backward sweep accumulates G1 itself (no kw_gsum, no rho)
     per_sample = {
         "kw_prepass": 8 + 8 * N + 8,                     # y in, N ring-score planes + the window sums W2 out
         "kw_vit": (8 + 8 * N) * warm + 4 * pw,           # y + ring scores in, packed back-pointers out
         "kw_fwd": (8 + 8 * N) * warm + 8 * (N + 2),      # ... la0, fref, N onset masses out
-        "kw_bwd": (8 + 8 * N) * warm + 8 + 8 * (N + 2) + 8 * N,   # y, ring scores, W2, forward outputs in; rho out
+        "kw_bwd": (8 + 8 * N) * warm + 8 + 8 * (N + 2) + (0 if fused else 8 * N),   # y, ring scores, W2, forward outputs in; rho out
         "kw_gsum": 8 + 8 * N,                            # y, rho in
         "kw_backtrace": 4 * pw * 1.25 + 2,               # psi (with walk-in) in, x out
         "kw_ll_partial": 8 + 2,
@@ -210,6 +211,7 @@ def main():
         plan.set_shard(o_lo, o_hi, first, last)
         args.pooled = True   # the shard statistics must be summed before the M-step
     info = plan.info()
+    info["ring_len"] = K - 1
     assert info["engine"] in (H.ENGINE_RING, H.ENGINE_WAVE)
     engine_name = {H.ENGINE_RING: "ring", H.ENGINE_WAVE: "wave"}[info["engine"]]
 

@@ -226,6 +226,7 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
     A(&r->Zc, nchT);
     A(&r->partS, nchT * (3 * N + 3));
     r->gparts = (int)((T + 4095) / 4096);
+    r->gparts = std::max<int>(r->gparts, g.nch);     // the fused backward sweep leaves one row per chain
     A(&r->partG, (int64_t)C * r->gparts * N * L);
     A(&r->yhead, C * (N * L + 2));
     A(&r->extra, C * 3 * N * L);

@@ -28,6 +28,7 @@
 namespace hmmsort {
 
 constexpr double kLn2 = 6.93147180559945286227e-01;
+typedef double wg_d4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double scale_of(double v, double s)  // s + log2-exponent of v, -inf for v <= 0
 {
@@ -300,7 +301,15 @@ struct BIn {
     double fref, la0; // fref(t+1), la0(t)
 };
 
-template <int N, bool UC>
+// FUSE (3-4 rings of at most 64 states): the spike-triggered sums G1[a][lag] = sum_t' rho_a(t') y(t' + lag) are
+// accumulated by the sweep itself on the matrix cores, so rho is not read back by a statistics kernel.  The sweep
+// runs backward in time; with sigma = step index (rising while t' falls) the product pairs rho(sigma) with
+// y(sigma - lag), i.e. with samples the sweep has already seen.  Per v_mfma_f64_16x16x4_f64:
+//   A[i][kk] = Y(tau + kk - 48 - i),  B[kk][a + 4 s'] = rho_a(tau + kk - 16 s')   =>  lag = 16 (3 - s') + i,
+// four delayed copies of the four rings fill the 16 columns, one accumulator tile holds all 64 lags.  rho and y
+// of the last ~128 steps live in two LDS rings of the wave; a super-step of W steps feeds W/4 MFMAs (the
+// remainder waits for the next one), and after the last step the copies are drained with zeros.
+template <int N, bool UC, bool FUSE = false>
 __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const WaveConst *__restrict__ cst,
                                                             const double *__restrict__ y,
                                                             const double *__restrict__ Rf,
@@ -312,9 +321,10 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
                                                             double *__restrict__ rho, double *__restrict__ partS,
                                                             double *__restrict__ Zc, double *__restrict__ bpre,
                                                             double *__restrict__ bown, double *__restrict__ yhead,
-                                                            double *__restrict__ trash)
+                                                            double *__restrict__ trash, double *__restrict__ partG)
 {
-    constexpr int D = N <= 4 ? 3 : (N <= 8 ? 2 : 1);
+    static_assert(!FUSE || (N >= 3 && N <= 4), "the fused statistics are written for four delayed copies of 3-4 rings");
+    constexpr int D = N <= 4 ? 3 : (N <= 8 ? 2 : 1);   // input pipeline depth in super-steps (4 with the fused statistics: spills, 0.70 ms)
     constexpr int KSC = 4, KCP0 = 4 + N, KPEND = 4 + 2 * N, KCPX = 4 + 3 * N, KSIZE = 4 + 3 * N + N * N;
     extern __shared__ double lds[];
     const int L = g.L, W = g.W, RB = g.RB, B = g.B;
@@ -338,6 +348,33 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
 
     for (int i = lane; i < N * (RB + 1); i += 64) DLv[i] = 1.0;
     for (int i = lane; i < RB + 1; i += 64) DLs[i] = 0.0;
+    // fused statistics: y ring (256 steps) | rho ring (128 steps x 4 rings, one padding row per 16)
+    double *YY = DLs + (RB + 1), *RG = YY + 256;
+    const int lk = lane >> 4, lj = lane & 15, gla = lj & 3, glsft = lj >> 2;
+    wg_d4 cacc = wg_d4{0.0, 0.0, 0.0, 0.0}, cacc2 = wg_d4{0.0, 0.0, 0.0, 0.0};   // two tiles: independent MFMA chains
+    int gtau = -1;                                       // next tau of the product, -1: no owned step yet
+    // products for tau = gtau, gtau + 4, ... while tau + 4 <= upto, two at a time on two accumulator tiles
+    // (independent MFMA chains).  Reading the operands of a whole super-step first and issuing 16 MFMAs back to
+    // back was slower (0.427 vs 0.400 ms: 64 more live VGPRs).
+    auto gmfma = [&](int upto) {
+        for (; gtau + 8 <= upto; gtau += 8) {
+            const int r0 = (gtau + lk - 16 * glsft) & 127, r1 = (gtau + 4 + lk - 16 * glsft) & 127;
+            const double b0 = RG[(r0 + (r0 >> 4)) * 4 + gla], b1 = RG[(r1 + (r1 >> 4)) * 4 + gla];
+            const double a0 = YY[(gtau + lk - 48 - lj) & 255], a1 = YY[(gtau + 4 + lk - 48 - lj) & 255];
+            cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, cacc, 0, 0, 0);
+            cacc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, cacc2, 0, 0, 0);
+        }
+        if (gtau + 4 <= upto) {
+            const int r0 = (gtau + lk - 16 * glsft) & 127;
+            const double b0 = RG[(r0 + (r0 >> 4)) * 4 + gla];
+            const double a0 = YY[(gtau + lk - 48 - lj) & 255];
+            cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, cacc, 0, 0, 0);
+            gtau += 4;
+        }
+    };
+    if (FUSE) {
+        for (int i = lane; i < 256 + 136 * 4; i += 64) YY[i] = 0.0;
+    }
     {
         const WaveConst &Kg = cst[ch];
         if (lane == 0) { KC[0] = Kg.sc0; KC[1] = Kg.mean0; KC[2] = 1.0 / Kg.den; KC[3] = Kg.P00; }
@@ -391,7 +428,8 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
         const bool live = lane < nact;
         const int64_t tb = te - 2 - done;                // time of lane 0
         const int64_t t = tb - lane;                     // step index i = done + 1 + lane, t = te-1-i
-        const bool owned = MODE == 1 || (MODE == 2 && done >= n_warm);   // wave-uniform
+        const bool owned = MODE == 1 || MODE == 3 || (MODE == 2 && done >= n_warm);   // wave-uniform
+        if (FUSE) YY[(done + 1 + lane) & 255] = d.y1;    // y of this lane's onset time t+1 (idle lanes: steps still to come)
         int ws = (done + 1) % RB + lane;                 // (done+1) % RB is wave-uniform
         ws = ws >= RB ? ws - RB : ws;
         int rs = ws - L;
@@ -486,10 +524,22 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
 #pragma unroll
             for (int a = 0; a < N; a++) {
                 const double rv = own1 ? (d.fv[a] * wa[a]) * gg[1] : 0.0;
-                *(live ? rhoc + (int64_t)a * T + t1 : trash + 64 * a + lane) = rv;
+                if (MODE != 3) *(live ? rhoc + (int64_t)a * T + t1 : trash + 64 * a + lane) = rv;
                 ra[a] += bulk ? rv : 0.0;
                 s2[a] = __builtin_fma(rv, d.w2, s2[a]);          // sum_k G2(a,k) (baumwelch.jl:302)
                 sx[a] += (own1 && t >= 0) ? wa[a] * gg[0] : 0.0;  // xi'_a(t+1): silent(t) -> (a,1)(t+1), :240
+                if (FUSE) {
+                    const int slot = (done + 1 + lane) & 127;
+                    RG[(slot + (slot >> 4)) * 4 + a] = rv;       // idle lanes: zeros at steps still to come
+                }
+            }
+            if (FUSE) {
+                if (N == 3) {
+                    const int slot = (done + 1 + lane) & 127;
+                    RG[(slot + (slot >> 4)) * 4 + 3] = 0.0;
+                }
+                if (gtau < 0) gtau = (done + 1) & ~3;            // wave-uniform
+                gmfma(done + 1 + nact);
             }
             if (MODE == 2 && c == 0 && t < L && live && t >= 0) {   // head of the recording: virtual onsets, pp
                 double lg[N + 1];
@@ -590,8 +640,32 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
     if (kwarm > kw1) sweep(kw1, kwarm, std::integral_constant<int, 2>());
     znorm();
     const int ko1 = nsteps - rk > kwarm ? nsteps - rk : kwarm;
-    if (ko1 > kwarm) sweep(kwarm, ko1, std::integral_constant<int, 1>());
+    if (FUSE) {
+        // rho itself is only read back near the chain ends (certificate windows, end-of-data terms of kw_edges):
+        // MODE 3 = MODE 1 without the rho stores for the bulk of the chain
+        const int km = kwarm + rk < ko1 ? kwarm + rk : ko1;
+        if (km > kwarm) sweep(kwarm, km, std::integral_constant<int, 1>());
+        if (ko1 > km) sweep(km, ko1, std::integral_constant<int, 3>());
+    } else if (ko1 > kwarm) sweep(kwarm, ko1, std::integral_constant<int, 1>());
     if (nsteps > ko1) sweep(ko1, nsteps, std::integral_constant<int, 2>());
+    if (FUSE) {
+        // drain: the delayed copies of the last steps still meet their y; rho of steps that never come is zero
+        const int sig_end = n_total + 1;
+        if (gtau >= 0) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const int slot = (sig_end + lane) & 127;
+                RG[(slot + (slot >> 4)) * 4 + a] = 0.0;
+            }
+            gmfma(sig_end + 52);                               // tau up to sig_end + 48
+        }
+        double *pg = partG + (int64_t)cg * N * L;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int lag = 16 * (3 - glsft) + lk + 4 * r;
+            if (gla < N && lag < L) pg[gla * L + lag] = cacc[r] + cacc2[r];
+        }
+    }
     // per-chain partial sums -> partS[cg][3N+3] = sx | ra | s2 | s_all s_m s_y2
     double *ps = partS + (int64_t)cg * (3 * N + 3);
 #pragma unroll
@@ -748,7 +822,6 @@ __global__ __launch_bounds__(256) void kw_gsum_generic(WaveGeom g, const double 
 // workgroup sweeps kGxSubs groups of 8 columns, wave w takes columns 2w, 2w+1 of a group.  Tiles of TR
 // rows go global -> registers -> LDS; the next tile's global loads are in flight during the MFMAs.
 // LDS rows of rho are padded by one row per 16 (the 4 delayed copies would otherwise hit one bank).
-typedef double wg_d4 __attribute__((ext_vector_type(4)));
 constexpr int kGxTR = 64, kGxBv = 512, kGxSubs = 1;
 
 // blockIdx.z = lag group: NT accumulator tiles of LPT lags each, starting at lag z NT LPT (models with more
@@ -915,21 +988,32 @@ __global__ __launch_bounds__(64) void kw_stats_final(WaveGeom g, int rowsG, cons
     const int NL = N * L, ws = 3 * N + 3, total = 3 * NL + N + 4;
     const double *pS = partS + (int64_t)ch * g.nch * ws;
     const double *pG = partG + (int64_t)ch * rowsG * NL;
+    // one column of a row-major partial table, rows strided over the lanes; eight loads in flight per lane (the
+    // kernel sits between the backward sweep and the M-step on the critical path: 0.05 -> 0.02 ms)
+    auto colsum = [&](const double *p, int rows, size_t stride) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+        int r = lane;
+        for (; r + 448 < rows; r += 512) {
+            a0 += p[(size_t)r * stride];         a1 += p[(size_t)(r + 64) * stride];
+            a2 += p[(size_t)(r + 128) * stride]; a3 += p[(size_t)(r + 192) * stride];
+            a4 += p[(size_t)(r + 256) * stride]; a5 += p[(size_t)(r + 320) * stride];
+            a6 += p[(size_t)(r + 384) * stride]; a7 += p[(size_t)(r + 448) * stride];
+        }
+        for (; r < rows; r += 64) a0 += p[(size_t)r * stride];
+        return ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    };
     double acc = 0.0;
     if (i < NL) {
-        const int a = i / L;
-        for (int r = lane; r < g.nch; r += 64) acc += pS[(size_t)r * ws + N + a];
+        acc = colsum(pS + N + i / L, g.nch, ws);
     } else if (i < 2 * NL) {
-        const int e = i - NL;
-        for (int r = lane; r < rowsG; r += 64) acc += pG[(size_t)r * NL + e];
+        acc = colsum(pG + (i - NL), rowsG, NL);
     } else if (i < 3 * NL) {
-        const int e = i - 2 * NL, a = e / L;
-        if (e % L == 0)
-            for (int r = lane; r < g.nch; r += 64) acc += pS[(size_t)r * ws + 2 * N + a];
+        const int e = i - 2 * NL;
+        if (e % L == 0) acc = colsum(pS + 2 * N + e / L, g.nch, ws);
     } else if (i < 3 * NL + N) {
-        for (int r = lane; r < g.nch; r += 64) acc += pS[(size_t)r * ws + (i - 3 * NL)];
+        acc = colsum(pS + (i - 3 * NL), g.nch, ws);
     } else if (i < 3 * NL + N + 3) {
-        for (int r = lane; r < g.nch; r += 64) acc += pS[(size_t)r * ws + 3 * N + (i - 3 * NL - N)];
+        acc = colsum(pS + 3 * N + (i - 3 * NL - N), g.nch, ws);
     }
     acc = wave_sum(acc);
     if (lane == 0) stats[(int64_t)ch * total + i] = acc + (i < 3 * NL ? extra[(int64_t)ch * 3 * NL + i] : 0.0);
@@ -989,9 +1073,16 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
     int rc = dispatch_N(N, [&](auto n) {
         constexpr int NN = decltype(n)::value;
         const size_t ldsf = ((size_t)(NN > 8 ? 1 : 2) * NN * (g.RB + 1) + 5 + 3 * NN + NN * NN) * sizeof(double);
-        const size_t ldsb = ((size_t)(NN + 1) * (g.RB + 1) + 4 + 3 * NN + NN * NN) * sizeof(double);
+        const bool generic = getenv("HMMSORT_GSUM_GENERIC") != nullptr;
+        // 3-4 rings of at most 64 states: the backward sweep accumulates G1 itself (matrix cores, LDS rings)
+        constexpr bool kCanFuse = NN == 3 || NN == 4;
+        const bool fuse = kCanFuse && L <= 64 && !generic && getenv("HMMSORT_GSUM_SEPARATE") == nullptr;
+        const size_t ldsb = ((size_t)(NN + 1) * (g.RB + 1) + 4 + 3 * NN + NN * NN + (fuse ? 256 + 136 * 4 : 0)) * sizeof(double);
         auto kf = r->uniform_cx ? kw_fwd<NN, true> : kw_fwd<NN, false>;
         auto kb = r->uniform_cx ? kw_bwd<NN, true> : kw_bwd<NN, false>;
+        if constexpr (kCanFuse) {
+            if (fuse) kb = r->uniform_cx ? kw_bwd<NN, true, true> : kw_bwd<NN, false, true>;
+        }
         int rc2;
         if ((rc2 = wave_lds_attr2(kf, ldsf)) || (rc2 = wave_lds_attr2(kb, ldsb))) return rc2;
         { WPROF(r, "kw_fwd", st);
@@ -999,7 +1090,7 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
                              r->FV, r->FREF, r->fpre, r->trash); }
         { WPROF(r, "kw_bwd", st);
           hipLaunchKernelGGL(kb, dim3(nchT), dim3(64), ldsb, st, g, r->d_cst, d_y, r->Rf, r->FA0, r->FV,
-                             r->FREF, r->fpre, r->W2, r->rho, r->partS, r->Zc, r->bpre, r->bown, r->yhead, r->trash); }
+                             r->FREF, r->fpre, r->W2, r->rho, r->partS, r->Zc, r->bpre, r->bown, r->yhead, r->trash, r->partG); }
         HS_HIP(hipGetLastError());
         // certificate + edge terms beside the statistics kernel
         HS_HIP(hipEventRecord(r->ev_a, st));
@@ -1017,8 +1108,9 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
         constexpr int NPx = NN <= 1 ? 1 : (NN <= 2 ? 2 : (NN <= 4 ? 4 : (NN <= 8 ? 8 : 16)));
         constexpr int LPTx = 16 * (16 / NPx), HSx = LPTx - 16;
         const int ntx = (L + LPTx - 1) / LPTx;
-        const bool generic = getenv("HMMSORT_GSUM_GENERIC") != nullptr;
-        if (!generic) {
+        if (fuse) {
+            rowsG = g.nch;                      // partG[ch][chain][N L], written by kw_bwd
+        } else if (!generic) {
             // up to 4 accumulator tiles per workgroup; longer rings take one pass over rho per group of 4
             const int ntk = NN > 8 ? 4 : (ntx < 4 ? ntx : 4), ngrp = (ntx + ntk - 1) / ntk;
             rowsG = (int)((g.T + kGxSubs * 8 * (int64_t)kGxBv - 1) / (kGxSubs * 8 * (int64_t)kGxBv));
