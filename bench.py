@@ -86,9 +86,13 @@ def measured_traffic(T, block):
             continue
         meta = d.get("_meta", {})
         if meta.get("kernel_sources") == want and meta.get("samples") == T and meta.get("block") == block:
+            measured_traffic.raw = d
             return {k: v["hbm_read_bytes"] + v["hbm_write_bytes"] for k, v in d.items() if k != "_meta"}, \
                 os.path.basename(path)
     return None, None
+
+
+measured_traffic.raw = None
 
 
 def cpu_baseline(H, N, K, temps, pp, sigma):
@@ -300,6 +304,19 @@ def main():
         # 78.6 TFLOP/s (MI355X_MICROARCH.md: FP32 vector 157.3 TF, fp64 at half rate)
         bound, peak, unit = "mfma", 78.6, "TFLOP/s"
         achieved = 4.0 * N * (K - 1) * T / (ksum[dom] * 1e-3) / 1e12
+    # the fused backward sweep (3-4 rings, <= 64 states) is not bound by one pipe: besides its HBM streams it
+    # issues the statistics product on the fp64 matrix cores and ~60 k vector instructions per wave
+    other_roofs = None
+    if dom == "kw_bwd" and info["engine"] == H.ENGINE_WAVE and N in (3, 4) and K - 1 <= 64:
+        other_roofs = {"mfma_fp64": {"achieved": 2.0 * N * (K - 1) * T / (ksum[dom] * 1e-3) / 1e12, "peak": 78.6,
+                                     "unit": "TFLOP/s (useful flops of G1)"}}
+        raw = measured_traffic.raw
+        if counters and raw and raw.get(dom, {}).get("valu_insts_per_wave"):
+            lane_ops = raw[dom]["valu_insts_per_wave"] * 64.0 * info["nchains"]
+            other_roofs["valu_fp64"] = {"achieved": lane_ops / ksum[dom] / 1e9, "peak": 35.0,
+                                        "unit": "G lane-instructions per ms (peak measured: scripts/micro/fma_probe.hip)"}
+        for v in other_roofs.values():
+            v["frac"] = v["achieved"] / v["peak"]
     step_bytes_model = sum(v for v in model.values() if v)
     step_bytes_counters = (sum(counters.get(k, 0.0) * prof[k][1] / nprof for k in ksum) if counters else None)
 
@@ -447,6 +464,7 @@ def main():
                          "traffic_model": model.get(dom),
                          "avg_launch_ms": ksum[dom],
                          "frac_contract": contract_bytes(S, T) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "other_roofs": other_roofs,
                          "step": {"ms": ms, "bytes_model": step_bytes_model, "bytes_counters": step_bytes_counters,
                                   "frac": (step_bytes_counters or step_bytes_model) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
                          "note": "frac = HBM bytes of the dominant kernel per launch (rocprofv3 FETCH_SIZE x2 + "
@@ -454,7 +472,8 @@ def main():
                                  "the kernel moves by design) / its HIP-event launch time / 8 TB/s; step.frac = "
                                  "the same over all kernels of one step and the wall time per step; "
                                  "frac_contract = SURVEY 8(d) trellis-materialising bytes (18 S + 28 per sample) "
-                                 "/ step time / peak: > 1 because no engine here writes the trellis"},
+                                 "/ step time / peak: > 1 because no engine here writes the trellis; other_roofs = "
+                                 "the dominant kernel against the pipes it also loads (fused backward sweep)"},
             "detail": {"viterbi_Msamples_s": T / t_vit / 1e6, "estep_Msamples_s": T / t_est / 1e6,
                        "kernel_ms": {k: round(v, 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1])},
                        "sum_kernel_ms_per_step": step_ms_kernels,
