@@ -326,7 +326,7 @@ int64_t wave_stats_len(const WaveDev *r) { return 3 * (int64_t)r->g.N * r->g.L +
 // Also accumulates sum y and sum y^2 per channel (magnitude of the reference's trellis, for the
 // near-tie threshold of the Viterbi sweep).
 // ------------------------------------------------------------------------------------------
-template <int N> constexpr int pre_rows() { return N <= 8 ? 8 : 4; }   // measured at N = 4: 4 rows 0.30 ms, 8 rows 0.19 ms, 16 rows 0.24 ms
+template <int N> constexpr int pre_rows() { return N <= 4 ? 8 : 4; }   // measured: N = 4: 4 rows 0.30 ms, 8 rows 0.19 ms, 16 rows 0.24 ms (10 M samples); N = 8: 8 rows 2.44 ms, 4 rows 1.92 ms (40 M)
 
 template <int N>
 __global__ __launch_bounds__(256) void kw_prepass(WaveGeom g, const WaveConst *__restrict__ cst,
