@@ -235,3 +235,26 @@ def test_train_model_loop_stays_on_device(O, H):
     assert len(seen) == 2 and np.array_equal(seen[0], mu0)
     assert np.allclose(mu_n, omu, rtol=1e-8, atol=1e-11) and abs(sig_n - osig) <= 1e-8 * osig
     assert np.allclose(sm_n.transitions["lp"], osm.val, rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("N,K,T", [(4, 60, 300_000), (3, 17, 50_001), (4, 65, 120_000)])
+def test_fused_statistics_equal_the_separate_kernel(H, N, K, T, monkeypatch):
+    # 3-4 rings of at most 64 states: the backward sweep accumulates the spike-triggered sums itself (matrix
+    # cores, LDS rings); HMMSORT_GSUM_SEPARATE forces the stand-alone statistics kernel on the same posteriors
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, 2.5 + 0.5 * i, 0.3 + 0.15 * i, 0.2) for i in range(N)], 1))
+    pp = [0.003, 0.001, 0.002, 0.0015][:N]
+    sm = H.StateMatrix.create(N, K, np.log(pp), False)
+    y = H.create_signal(T, 0.3, pp, temps, seed=N * K)
+    mu0 = np.asfortranarray(temps * 0.9)
+    mu0[0, :] = 0
+    H.set_option("plan_cache", 0)
+    try:
+        fused = H.train_step(y, sm, mu0.copy(order="F"), 0.35)
+        monkeypatch.setenv("HMMSORT_GSUM_SEPARATE", "1")
+        separate = H.train_step(y, sm, mu0.copy(order="F"), 0.35)
+    finally:
+        monkeypatch.delenv("HMMSORT_GSUM_SEPARATE", raising=False)
+        H.set_option("plan_cache", 4)
+    assert np.allclose(fused[1], separate[1], rtol=1e-11, atol=1e-13), np.abs(fused[1] - separate[1]).max()
+    assert abs(fused[2] - separate[2]) <= 1e-12 * separate[2]
+    assert np.allclose(fused[0].transitions["lp"], separate[0].transitions["lp"], rtol=1e-12, atol=1e-14)
