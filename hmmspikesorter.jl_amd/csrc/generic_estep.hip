@@ -27,6 +27,7 @@
 // sigma follows from  sum_t sum_j (y_t - m_j)^2 gamma_j(t) = sum y^2 - 2 sum_j m_j G1_j + sum_j m_j^2 G0_j.
 #include <cmath>
 
+#include "fastmath.h"
 #include "generic_dev.h"
 #include "hmmsort_internal.h"
 
@@ -65,8 +66,10 @@ __device__ __forceinline__ double wmax(double v)
 // red[par][slot][wave]: slot 0 column sum, 1 emission exponent maximum of the NEXT column, 2 gamma normaliser
 constexpr int kRedW = 16;
 
-template <int SPT>
-__global__ __launch_bounds__(1024) void bes_block(BesArgs a)
+// NTH = threads per workgroup (the launch bound decides the register budget: 512 threads leave 256 VGPRs per
+// lane, which the per-state constants of 8 states per thread need; under a 1024-thread bound they spill 776 B)
+template <int SPT, int NTH>
+__global__ __launch_bounds__(NTH) void bes_block(BesArgs a)
 {
     extern __shared__ double sh[];
     const int S = a.S, B = a.B, H = a.H, tid = threadIdx.x, nt = blockDim.x;
@@ -74,9 +77,15 @@ __global__ __launch_bounds__(1024) void bes_block(BesArgs a)
     double *col[2] = {sh, sh + S};
     double *red = sh + 2 * S;                      // [2][3][kRedW]
     double *xterm = red + 2 * 3 * kRedW;           // [2][nsrc1]
+    double *xw = xterm + 2 * a.nsrc1, *xd = xw + a.nsrc1;   // the silent state's outgoing transitions: weight, destination
+    for (int i = tid; i < a.nsrc1; i += nt) { xw[i] = a.out_w[i]; xd[i] = (double)a.out_dst[i]; }
     const int64_t T = a.T;
-    double m[SPT], en[SPT];
-    int p0[SPT], p1[SPT], q0[SPT], q1[SPT];
+    // per-thread constants of its SPT states.  93 % of the states of an overlap model have ONE incoming and one
+    // outgoing transition (the interior of the pair lattice): the first edge of each list lives in registers, the
+    // rest of a list is read from the (L2-resident) CSR arrays -- one dependent global load per edge and step was
+    // what bounded the first version (98 -> see DESIGN 3.1c)
+    double m[SPT], en[SPT], wi0[SPT], wo0[SPT];
+    int p0[SPT], p1[SPT], q0[SPT], q1[SPT], si0[SPT], do0[SPT];
 #pragma unroll
     for (int k = 0; k < SPT; k++) {
         const int j = tid + k * nt;
@@ -84,6 +93,10 @@ __global__ __launch_bounds__(1024) void bes_block(BesArgs a)
         m[k] = ok ? a.mean[j] : 0.0;
         p0[k] = ok ? a.in_ptr[j] : 0;  p1[k] = ok ? a.in_ptr[j + 1] : 0;
         q0[k] = ok ? a.out_ptr[j] : 0; q1[k] = ok ? a.out_ptr[j + 1] : 0;
+        const bool hi = p1[k] > p0[k], ho = q1[k] > q0[k];
+        si0[k] = hi ? a.in_src[p0[k]] : 0;  wi0[k] = hi ? a.in_w[p0[k]] : 0.0;
+        do0[k] = ho ? a.out_dst[q0[k]] : 0; wo0[k] = ho ? a.out_w[q0[k]] : 0.0;
+        p0[k] += hi; q0[k] += ho;             // the lists now start at their second edge
     }
     double *win = a.win + (size_t)blockIdx.x * B * S;
 
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(1024) void bes_block(BesArgs a)
             for (int k = 0; k < SPT; k++) {
                 const int j = tid + k * nt;
                 if (j < S) {
-                    const double v = exp(en[k] - emax);
+                    const double v = fexp(en[k] - emax);
                     col[0][j] = v;
                     ps += v;
                     if (t0 >= lo) win[j] = v;
@@ -143,11 +156,13 @@ __global__ __launch_bounds__(1024) void bes_block(BesArgs a)
             }
             reduce3(0, ps, pm, 0.0);
             int par = 0;
+            double ynext = a.y[(t0 + 2) < T ? (t0 + 2) : T - 1];   // global loads run one step ahead of their use
             for (int64_t t = t0 + 1; t < hi; t++) {
+                const double yn = ynext;                            // y[t + 1]
+                ynext = a.y[(t + 2) < T ? (t + 2) : T - 1];
                 __syncthreads();
                 read3(par, s, emax, z);
                 const double inv = 1.0 / s;
-                const double yn = a.y[(t + 1) < T ? (t + 1) : t];
                 const double *prev = col[par];
                 double *cur = col[par ^ 1];
                 ps = 0.0; pm = -INFINITY;
@@ -155,9 +170,9 @@ __global__ __launch_bounds__(1024) void bes_block(BesArgs a)
                 for (int k = 0; k < SPT; k++) {
                     const int j = tid + k * nt;
                     if (j < S) {
-                        double acc = 0.0;
+                        double acc = prev[si0[k]] * wi0[k];
                         for (int e = p0[k]; e < p1[k]; e++) acc += prev[a.in_src[e]] * a.in_w[e];   // :47
-                        const double v = (acc * inv) * exp(en[k] - emax);
+                        const double v = (acc * inv) * fexp(en[k] - emax);
                         cur[j] = v;
                         ps += v;
                         if (t >= lo) win[(size_t)(t - lo) * S + j] = v;
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(1024) void bes_block(BesArgs a)
                             if (te == lo) rec[4 * S + j] = cur;
                         }
                         if (te == hi) rec[3 * S + j] = cur;
-                        col[0][j] = cur * exp(en[k] - emax);
+                        col[0][j] = cur * fexp(en[k] - emax);
                         const double d = yp - m[k];
                         en[k] = -(d * d) * a.rden;
                         pm = fmax(pm, en[k]);
@@ -222,13 +237,32 @@ __global__ __launch_bounds__(1024) void bes_block(BesArgs a)
             reduce3(0, ps, pm, pz);
             int par = 0;
             int64_t tprev = te;                    // time whose g[] / xterm wait for their normaliser
+            // global loads one step ahead: y[t-1] for the next emissions, alpha(t) of the owned samples
+            double y_cur = a.y[te], y_m1 = a.y[te > 0 ? te - 1 : 0], y_m2 = a.y[te > 1 ? te - 2 : 0];
+            double alc[SPT];
+#pragma unroll
+            for (int k = 0; k < SPT; k++) {
+                const int j = tid + k * nt;
+                alc[k] = (j < S && te - 1 < hi && te - 1 >= lo) ? win[(size_t)(te - 1 - lo) * S + j] : 0.0;
+            }
             for (int64_t t = te - 1; t >= lo; t--) {
+                // y_cur = y[t+1], y_m1 = y[t], y_m2 = y[t-1]; alc = alpha(t)
+                const double yv = y_cur, yp = y_m2;
+                y_cur = y_m1; y_m1 = y_m2;
+                y_m2 = a.y[t > 1 ? t - 2 : 0];
+                double aln[SPT];
+                const bool own_next = t - 1 < hi && t - 1 >= lo;
+#pragma unroll
+                for (int k = 0; k < SPT; k++) {
+                    const int j = tid + k * nt;
+                    aln[k] = (j < S && own_next) ? win[(size_t)(t - 1 - lo) * S + j] : 0.0;
+                }
                 __syncthreads();
                 read3(par, s, emax, z);
                 const double inv = 1.0 / s;
-                // lagged statistics of time tprev (its normaliser z has just arrived)
+                // lagged statistics of time tprev = t + 1 (its normaliser z has just arrived)
                 if (tprev < hi) {
-                    const double rz = 1.0 / z, yv = a.y[tprev];
+                    const double rz = 1.0 / z;
 #pragma unroll
                     for (int k = 0; k < SPT; k++) {
                         const int j = tid + k * nt;
@@ -244,7 +278,6 @@ __global__ __launch_bounds__(1024) void bes_block(BesArgs a)
                         if (tid == 0) Gam0 += g[0] * rz;
                     }
                 }
-                const double yp = a.y[t > 0 ? t - 1 : 0];
                 const double *nxt = col[par];
                 double *out = col[par ^ 1];
                 const bool own = t < hi;
@@ -253,20 +286,20 @@ __global__ __launch_bounds__(1024) void bes_block(BesArgs a)
                 for (int k = 0; k < SPT; k++) {
                     const int j = tid + k * nt;
                     if (j < S) {
-                        double cur = 0.0;
+                        double cur = nxt[do0[k]] * wo0[k];
                         for (int e = q0[k]; e < q1[k]; e++) cur += nxt[a.out_dst[e]] * a.out_w[e];   // :94
                         ps += cur;
                         if (own) {
-                            const double al = win[(size_t)(t - lo) * S + j];
+                            const double al = alc[k];
                             g[k] = al * cur;
                             pz += g[k];
                             if (t == lo) rec[4 * S + j] = cur;
                             if (j == 0 && t <= T - 2)
                                 for (int i = 0; i < a.nsrc1; i++)   // :240  alpha_1(t) a_1j b_j(t+1) beta_j(t+1)
-                                    xterm[(par ^ 1) * a.nsrc1 + i] = al * (nxt[a.out_dst[i]] * a.out_w[i]);
+                                    xterm[(par ^ 1) * a.nsrc1 + i] = al * (nxt[(int)xd[i]] * xw[i]);
                         }
                         if (t == hi) rec[3 * S + j] = cur;
-                        out[j] = (cur * inv) * exp(en[k] - emax);
+                        out[j] = (cur * inv) * fexp(en[k] - emax);
                         const double d = yp - m[k];
                         en[k] = -(d * d) * a.rden;
                         pm = fmax(pm, en[k]);
@@ -275,12 +308,14 @@ __global__ __launch_bounds__(1024) void bes_block(BesArgs a)
                 par ^= 1;
                 reduce3(par, ps, pm, pz);
                 tprev = t;
+#pragma unroll
+                for (int k = 0; k < SPT; k++) alc[k] = aln[k];
             }
             // flush the statistics of the block's first sample
             __syncthreads();
             read3(par, s, emax, z);
             if (tprev < hi) {
-                const double rz = 1.0 / z, yv = a.y[tprev];
+                const double rz = 1.0 / z, yv = y_cur;              // y[tprev]
 #pragma unroll
                 for (int k = 0; k < SPT; k++) {
                     const int j = tid + k * nt;
@@ -440,7 +475,7 @@ bool blocked_estep_supported(const GenericDev *g)
 {
     // two columns of S doubles + reduction scratch in LDS; 16 states per thread at 1024 threads
     return g->blocked && g->nsrc1 >= 1 && g->nsrc1 <= 256 && g->T >= 2 &&
-           (2 * (size_t)g->S + 2 * 3 * kRedW + 2 * (size_t)g->nsrc1) * 8 <= 156 * 1024 && g->S <= 16 * 1024;
+           (2 * (size_t)g->S + 2 * 3 * kRedW + 4 * (size_t)g->nsrc1) * 8 <= 156 * 1024 && g->S <= 16 * 1024;
 }
 
 int64_t blocked_stats_len(const GenericDev *g) { return 2 * g->S + g->nsrc1 + 2; }
@@ -454,7 +489,7 @@ int blocked_estep(GenericDev *g, const double *d_y, double *d_stats, hipStream_t
     int dev = 0, ncu = 256;
     HS_HIP(hipGetDevice(&dev));
     HS_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    const size_t lds = (2 * S + 2 * 3 * kRedW + 2 * (size_t)g->nsrc1) * sizeof(double);
+    const size_t lds = (2 * S + 2 * 3 * kRedW + 4 * (size_t)g->nsrc1) * sizeof(double);
     const int per_cu = lds <= 76 * 1024 && nt <= 512 ? 2 : 1;
     const int grid = (int)std::min<size_t>(nb, (size_t)ncu * per_cu);
     int rc;
@@ -483,8 +518,12 @@ int blocked_estep(GenericDev *g, const double *d_y, double *d_stats, hipStream_t
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, st, a);
         return HMMSORT_OK;
     };
-    rc = spt <= 1 ? launch(bes_block<1>) : spt <= 2 ? launch(bes_block<2>) : spt <= 4 ? launch(bes_block<4>)
-         : spt <= 8 ? launch(bes_block<8>) : launch(bes_block<16>);
+    // register budget by launch bound: 1-2 states per thread fit 128 VGPRs (bound 1024: more waves per SIMD,
+    // S = 900: 15.5 against 22 ms per 10^6 samples); 4-8 states per thread need the 256 of a 512-thread bound
+    // (S = 3600: 54 against 96 ms)
+    if (nt <= 512) rc = spt <= 1 ? launch(bes_block<1, 1024>) : spt <= 2 ? launch(bes_block<2, 1024>)
+                        : spt <= 4 ? launch(bes_block<4, 512>) : launch(bes_block<8, 512>);
+    else rc = spt <= 8 ? launch(bes_block<8, 1024>) : launch(bes_block<16, 1024>);
     if (rc) return rc;
     HS_HIP(hipGetLastError());
     if (nb > 1)
