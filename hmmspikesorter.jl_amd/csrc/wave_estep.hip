@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
                 s_y2 = __builtin_fma(ga, d.y0 * d.y0, s_y2);     // :302 with the new silent mean (= 0)
             }
             const bool own1 = live && t1 >= g.own_lo && t1 < g.own_hi;
-            const bool bulk = !(g.last && t1 > T - L);           // truncated rings: summed per phase in kw_edges
+            const bool bulk = !(g.last && t1 > T - L);           // truncated rings: summed per phase in kw_stats_final
 #pragma unroll
             for (int a = 0; a < N; a++) {
                 const double rv = own1 ? (d.fv[a] * wa[a]) * gg[1] : 0.0;
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
     znorm();
     const int ko1 = nsteps - rk > kwarm ? nsteps - rk : kwarm;
     if (FUSE) {
-        // rho itself is only read back near the chain ends (certificate windows, end-of-data terms of kw_edges):
+        // rho itself is only read back near the chain ends (certificate windows, end-of-data terms of kw_stats_final):
         // MODE 3 = MODE 1 without the rho stores for the bulk of the chain
         const int km = kwarm + rk < ko1 ? kwarm + rk : ko1;
         if (km > kwarm) sweep(kwarm, km, std::integral_constant<int, 1>());
@@ -935,57 +935,19 @@ __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__re
     }
 }
 
-// virtual onsets t' = -j (rings already running at the first sample), the end-of-data correction of
-// G0 and pp = gamma[:,1] (baumwelch.jl:263).  One thread per ring state, one block row per channel.
-//   extra[0..NL)    = G0 of the virtual onsets + sum of rho over the onsets of the last L-1 samples
-//                     that still reach phase k (kw_bwd leaves those out of its total)
-//   extra[NL..2NL)  = G1 of the virtual onsets,  extra[2NL..3NL) = G2 of the virtual onsets
-__global__ __launch_bounds__(64) void kw_edges(WaveGeom g, const double *__restrict__ y,
-                                               const double *__restrict__ Rf, const double *__restrict__ virt,
-                                               const double *__restrict__ FA0, const double *__restrict__ rho,
-                                               const double *__restrict__ Zc, const double *__restrict__ yhead,
-                                               double *__restrict__ extra, double *__restrict__ pp)
-{
-    const int L = g.L, N = g.N, NL = N * L, ch = blockIdx.y, S = 1 + NL;
-    const int64_t T = g.T;
-    const double *yc = y + (int64_t)ch * T, *rc = rho + (int64_t)ch * N * T;
-    const double *yh = yhead + (int64_t)ch * (NL + 2);
-    const double z = Zc[(int64_t)ch * g.nch];
-    for (int pair = blockIdx.x * blockDim.x + threadIdx.x; pair < NL; pair += gridDim.x * blockDim.x) {
-        const int a = pair / L, k = pair % L + 1;
-        const double *V = virt + ((int64_t)ch * N + a) * (L + 1);
-        double g0 = 0.0, g1 = 0.0, g2 = 0.0;
-        for (int j = 1; j <= L - 1 && g.first; j++) {  // virtual onsets exist at the recording start only
-            const int idx = -j + k - 1;
-            if (idx < 0) continue;
-            const double rv = fexp((V[j] + yh[a * L + (L - 1 - j)]) - z);
-            const double yv = yc[idx];
-            g0 += rv; g1 += rv * yv; g2 += rv * (yv * yv);
-        }
-        double tail = 0.0;
-        if (g.last)
-            for (int64_t t = T - L + 1; t <= T - k; t++)
-                if (t >= 0) tail += rc[(int64_t)a * T + t];
-        double *ex = extra + (int64_t)ch * 3 * NL;
-        ex[pair] = g0 + tail;
-        ex[NL + pair] = g1;
-        ex[2 * NL + pair] = g2;
-        const double lpv = k == 1 ? Rf[((int64_t)ch * N + a) * T] : V[k - 1];
-        pp[(int64_t)ch * S + 1 + pair] = (lpv + yh[a * L + (L - k)]) - z;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) pp[(int64_t)ch * S] = (FA0[(int64_t)ch * T] + yh[NL]) - z;
-}
-
 // deterministic final assembly: stats[ch] = [G0 | G1 | G2 | Xi' | s_all | s_m | s_y2 | 0].
 // G2 only enters the M-step through its sum over all ring states (sigma, baumwelch.jl:297-307), so the
 // real onsets' share sum_k G2(a,k) = sum_t' rho_a(t') W2(t') is kept in entry (a, 1) and the other
 // entries only hold the virtual onsets' terms.
 __global__ __launch_bounds__(64) void kw_stats_final(WaveGeom g, int rowsG, const double *__restrict__ partG,
-                                                     const double *__restrict__ partS,
-                                                     const double *__restrict__ extra, double *__restrict__ stats)
+                                                     const double *__restrict__ partS, const double *__restrict__ y,
+                                                     const double *__restrict__ Rf, const double *__restrict__ virt,
+                                                     const double *__restrict__ FA0, const double *__restrict__ rho,
+                                                     const double *__restrict__ Zc, const double *__restrict__ yhead,
+                                                     double *__restrict__ pp, double *__restrict__ stats)
 {
     const int N = g.N, L = g.L, i = blockIdx.x, ch = blockIdx.y, lane = threadIdx.x;
-    const int NL = N * L, ws = 3 * N + 3, total = 3 * NL + N + 4;
+    const int NL = N * L, ws = 3 * N + 3, total = 3 * NL + N + 4, S = 1 + NL;
     const double *pS = partS + (int64_t)ch * g.nch * ws;
     const double *pG = partG + (int64_t)ch * rowsG * NL;
     // one column of a row-major partial table, rows strided over the lanes; eight loads in flight per lane (the
@@ -1015,8 +977,37 @@ __global__ __launch_bounds__(64) void kw_stats_final(WaveGeom g, int rowsG, cons
     } else if (i < 3 * NL + N + 3) {
         acc = colsum(pS + 3 * N + (i - 3 * NL - N), g.nch, ws);
     }
+    // edge terms of this entry (the block's lanes share the loop a separate kernel used to run serially per entry,
+    // on the critical path between the backward sweep and the M-step): virtual onsets t' = -j at the start of the
+    // recording, the end-of-data correction of G0, and pp = gamma[:,1] (baumwelch.jl:263)
+    if (i < 3 * NL) {
+        const int64_t T = g.T;
+        const int pair = i % NL, which = i / NL, a = pair / L, k = pair % L + 1;
+        const double *yc = y + (int64_t)ch * T, *rc = rho + (int64_t)ch * N * T;
+        const double *yh = yhead + (int64_t)ch * (NL + 2);
+        const double *V = virt + ((int64_t)ch * N + a) * (L + 1);
+        const double z = Zc[(int64_t)ch * g.nch];
+        if (g.first)
+            for (int j = 1 + lane; j <= L - 1; j += 64) {
+                const int idx = -j + k - 1;
+                if (idx < 0) continue;
+                const double rv = fexp((V[j] + yh[a * L + (L - 1 - j)]) - z);
+                const double yv = yc[idx];
+                acc += which == 0 ? rv : (which == 1 ? rv * yv : rv * (yv * yv));
+            }
+        if (which == 0) {
+            if (g.last)
+                for (int64_t t = T - L + 1 + lane; t <= T - k; t += 64)
+                    if (t >= 0) acc += rc[(int64_t)a * T + t];
+            if (lane == 0) {
+                const double lpv = k == 1 ? Rf[((int64_t)ch * N + a) * T] : V[k - 1];
+                pp[(int64_t)ch * S + 1 + pair] = (lpv + yh[a * L + (L - k)]) - z;
+                if (pair == 0) pp[(int64_t)ch * S] = (FA0[(int64_t)ch * T] + yh[NL]) - z;
+            }
+        }
+    }
     acc = wave_sum(acc);
-    if (lane == 0) stats[(int64_t)ch * total + i] = acc + (i < 3 * NL ? extra[(int64_t)ch * 3 * NL + i] : 0.0);
+    if (lane == 0) stats[(int64_t)ch * total + i] = acc;
 }
 
 // M-step finish (baumwelch.jl:262-307) from the (possibly all-reduced) statistics.
@@ -1092,19 +1083,15 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
           hipLaunchKernelGGL(kb, dim3(nchT), dim3(64), ldsb, st, g, r->d_cst, d_y, r->Rf, r->FA0, r->FV,
                              r->FREF, r->fpre, r->W2, r->rho, r->partS, r->Zc, r->bpre, r->bown, r->yhead, r->trash, r->partG); }
         HS_HIP(hipGetLastError());
-        // certificate + edge terms beside the statistics kernel
+        // the certificate runs beside the statistics / final assembly
         HS_HIP(hipEventRecord(r->ev_a, st));
         HS_HIP(hipStreamWaitEvent(r->side, r->ev_a, 0));
-        { WPROF(r, "kw_edges", r->side);
-          hipLaunchKernelGGL(kw_edges, dim3((NL + 63) / 64, g.C), dim3(64), 0, r->side, g, d_y, r->Rf, r->virt, r->FA0,
-                             r->rho, r->Zc, r->yhead, r->extra, r->pp); }
-        HS_HIP(hipEventRecord(r->ev_b, r->side));   // the final assembly waits for the edge terms only ...
         if (g.nch > 1) {
             WPROF(r, "kw_fb_check", r->side);
             hipLaunchKernelGGL(kw_fb_check, dim3(nchT), dim3(64), 0, r->side, g, 1e-9, r->FA0, r->FV, r->FREF, r->fpre,
                                r->bpre, r->bown, r->rho, r->diag, r->dbg);
         }
-        HS_HIP(hipEventRecord(r->ev_c, r->side));   // ... the certificate only has to be done when the call's work is
+        HS_HIP(hipEventRecord(r->ev_c, r->side));   // the certificate only has to be done when the call's work is
         constexpr int NPx = NN <= 1 ? 1 : (NN <= 2 ? 2 : (NN <= 4 ? 4 : (NN <= 8 ? 8 : 16)));
         constexpr int LPTx = 16 * (16 / NPx), HSx = LPTx - 16;
         const int ntx = (L + LPTx - 1) / LPTx;
@@ -1139,11 +1126,10 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
         return HMMSORT_OK;
     });
     if (rc) return rc;
-    HS_HIP(hipStreamWaitEvent(st, r->ev_b, 0));
     const int total = 3 * NL + N + 4;
     { WPROF(r, "kw_stats_final", st);
-      hipLaunchKernelGGL(kw_stats_final, dim3(total, g.C), dim3(64), 0, st, g, rowsG, r->partG, r->partS, r->extra,
-                         d_stats); }
+      hipLaunchKernelGGL(kw_stats_final, dim3(total, g.C), dim3(64), 0, st, g, rowsG, r->partG, r->partS, d_y, r->Rf,
+                         r->virt, r->FA0, r->rho, r->Zc, r->yhead, r->pp, d_stats); }
     HS_HIP(hipStreamWaitEvent(st, r->ev_c, 0));
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
