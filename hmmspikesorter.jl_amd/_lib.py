@@ -69,7 +69,9 @@ SIGNATURES = {
     "hmmsort_plan_stats_len": (_i64, [_vp]),
     "hmmsort_plan_set_shard": (_int, [_vp, _i64, _i64, _int, _int]),
     "hmmsort_plan_mstep": (_int, [_vp, _vp, _vp, _vp]),
+    "hmmsort_plan_mstep_len": (_i64, [_vp]),
     "hmmsort_plan_diagnostics": (_int, [_vp, _vp, _pi64]),
+    "hmmsort_plan_tie_stats": (_int, [_vp, _vp, _pi64]),
     "hmmsort_plan_extract_spiketimes": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "hmmsort_plan_reconstruct": (_int, [_vp, _vp, _vp, _vp]),
     "hmmsort_plan_unroll_mlseq": (_int, [_vp, _vp, _vp, _vp]),

@@ -27,17 +27,30 @@ namespace {
 
 struct DevBuf {  // RAII device buffer for the host-pointer entry points
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    size_t cap = 0;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
     int alloc(size_t bytes)
     {
-        if (hipMalloc(&p, std::max<size_t>(bytes, 8)) != hipSuccess) {
+        release();
+        bytes = std::max<size_t>(bytes, 8);
+        if (hipMalloc(&p, bytes) != hipSuccess) {
             (void)hipGetLastError();
             set_error("hipMalloc of %zu bytes failed", bytes);
             p = nullptr;
             return HMMSORT_ENOMEM;
         }
+        cap = bytes;
         return HMMSORT_OK;
     }
+    // cached buffers of a host slot: keep when large enough, else replace (a re-armed or rebuilt plan may
+    // need more: blocked statistics grow with the finite entry transitions, a wave plan needs 3NL+N+4)
+    int ensure(size_t bytes) { return (p && cap >= std::max<size_t>(bytes, 8)) ? HMMSORT_OK : alloc(bytes); }
     template <typename Tv> Tv *as() { return static_cast<Tv *>(p); }
 };
 
@@ -249,6 +262,12 @@ int hmmsort_set_option(const char *key, int64_t value)
     } else if (!strcmp(key, "strict_limit_mb")) {
         HS_CHECK(value >= 0, HMMSORT_EINVAL, "set_option: strict_limit_mb must be >= 0");
         options_modify([&](Options &o) { o.strict_limit_mb = value; });
+    } else if (!strcmp(key, "tie_scale")) {
+        HS_CHECK(value >= 1, HMMSORT_EINVAL, "set_option: tie_scale must be >= 1");
+        options_modify([&](Options &o) { o.tie_scale = value; });
+    } else if (!strcmp(key, "tie_debug")) {
+        HS_CHECK(value >= 0 && value <= 3, HMMSORT_EINVAL, "set_option: tie_debug must be 0..3");
+        options_modify([&](Options &o) { o.tie_debug = value; });
     } else if (!strcmp(key, "plan_cache")) {
         HS_CHECK(value >= 0 && value <= 64, HMMSORT_EINVAL, "set_option: plan_cache must be 0..64");
         options_modify([&](Options &o) { o.plan_cache = value; });
@@ -270,6 +289,8 @@ int hmmsort_get_option(const char *key, int64_t *value)
     else if (!strcmp(key, "escalate")) *value = o.escalate;
     else if (!strcmp(key, "plan_cache")) *value = o.plan_cache;
     else if (!strcmp(key, "strict_limit_mb")) *value = o.strict_limit_mb;
+    else if (!strcmp(key, "tie_scale")) *value = o.tie_scale;
+    else if (!strcmp(key, "tie_debug")) *value = o.tie_debug;
     else if (!strcmp(key, "last_escalations")) *value = last_escalations();
     else {
         set_error("get_option: unknown key '%s'", key);
@@ -474,6 +495,17 @@ int64_t hmmsort_plan_stats_len(const hmmsort_plan *p)
     return ring_stats_len(p->ring);
 }
 
+// [mu K*N | sigma | lp_new | pp S] per channel: the wave and ring M-step kernels always write N entry
+// log-probabilities (a template whose entry transitions were dropped from the list keeps its slot);
+// the generic/blocked engines one per transition leaving state 1 except the first (baumwelch.jl:226,264)
+int64_t hmmsort_plan_mstep_len(const hmmsort_plan *p)
+{
+    if (!p) return 0;
+    const HostModel &m = p->model;
+    const int64_t nlp = (p->wave || p->ring) ? m.N : (p->gen ? generic_n_lp(p->gen) : 0);
+    return m.K * m.N + 1 + nlp + m.S;
+}
+
 int hmmsort_plan_estep(hmmsort_plan *p, const double *d_y, double *d_stats, void *stream)
 {
     HS_CHECK(p && d_y && d_stats, HMMSORT_EINVAL, "plan_estep: null argument");
@@ -503,6 +535,14 @@ int hmmsort_plan_diagnostics(hmmsort_plan *p, void *stream, int64_t diag[8])
     return HMMSORT_OK;
 }
 
+int hmmsort_plan_tie_stats(hmmsort_plan *p, void *stream, int64_t out[8])
+{
+    HS_CHECK(p && out, HMMSORT_EINVAL, "plan_tie_stats: null argument");
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    if (p->wave) return wave_tie_stats(p->wave, (hipStream_t)stream, out);
+    return HMMSORT_OK;
+}
+
 // debugging aid (not part of the documented ABI): raw debug record of the wave engine
 int hmmsort_plan_debug_record(hmmsort_plan *p, double *out64)
 {
@@ -513,15 +553,20 @@ int hmmsort_plan_debug_record(hmmsort_plan *p, double *out64)
 }
 
 // debugging aid (not part of the documented ABI): copy an internal per-sample array of a wave plan
-// which: 0 FA0 (log alpha silent), 1 FREF, 2 FV (N x T), 3 rho (N x T), 4 Rf (N x T)
+// which: 0 FA0 (log alpha silent), 1 FREF, 2 FV (N x T), 3 rho (N x T), 4 Rf (N x T), 5 vend, 6 vpre (chain records), 7 exact trellis values of the decoded path at block starts (wave_ties.hip)
 int hmmsort_plan_debug_array(hmmsort_plan *p, int which, double *out, int64_t n)
 {
     HS_CHECK(p && out && p->wave, HMMSORT_EINVAL, "plan_debug_array: needs a wave plan");
     HS_HIP(hipDeviceSynchronize());
     const WaveDev *w = p->wave;
-    const double *src = which == 0 ? w->FA0 : which == 1 ? w->FREF : which == 2 ? w->FV : which == 3 ? w->rho :
-                        which == 4 ? w->Rf : which == 5 ? w->vend : w->vpre;
-    HS_HIP(hipMemcpy(out, src, n * sizeof(double), hipMemcpyDeviceToHost));
+    const int64_t CT = (int64_t)w->g.C * w->g.T, NCT = CT * w->g.N;
+    const int64_t rec = (int64_t)w->g.C * w->g.nch * (1 + (int64_t)w->g.N * w->g.L);
+    const double *srcs[8] = {w->FA0, w->FREF, w->FV, w->rho, w->Rf, w->vend, w->vpre, w->tie_v};
+    const int64_t lens[8] = {CT, CT, NCT, NCT, NCT, rec, rec, (int64_t)w->g.C * (w->tie_nblk + 1)};
+    HS_CHECK(which >= 0 && which < 8, HMMSORT_EINVAL, "plan_debug_array: unknown array %d", which);
+    HS_CHECK(n >= 0 && n <= lens[which], HMMSORT_EINVAL, "plan_debug_array: %lld entries asked, array %d holds %lld",
+             (long long)n, which, (long long)lens[which]);
+    HS_HIP(hipMemcpy(out, srcs[which], n * sizeof(double), hipMemcpyDeviceToHost));
     return HMMSORT_OK;
 }
 
@@ -587,9 +632,9 @@ static int viterbi_host(const void *y, int sample_type, int64_t T, const int16_t
     std::unique_ptr<HostSlot> slot = take_slot(T, states, N, K, S, opt);
     if (!slot) slot = new_slot(T, opt);
     HostSlot &h = *slot;
-    if (!h.dy.p && (rc = h.dy.alloc(T * sizeof(double)))) return rc;
-    if (!h.dx.p && (rc = h.dx.alloc(T * sizeof(int16_t)))) return rc;
-    if (!h.dll.p && (rc = h.dll.alloc(sizeof(double)))) return rc;
+    if ((rc = h.dy.ensure(T * sizeof(double)))) return rc;
+    if ((rc = h.dx.ensure(T * sizeof(int16_t)))) return rc;
+    if ((rc = h.dll.ensure(sizeof(double)))) return rc;
     if (sample_type == HMMSORT_SAMPLES_F64) {
         HS_HIP(hipMemcpy(h.dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
     } else {
@@ -781,7 +826,7 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
     std::unique_ptr<HostSlot> slot = take_slot(T, states, N, K, S, opt);
     if (!slot) slot = new_slot(T, opt);
     HostSlot &h = *slot;
-    if (!h.dy.p && (rc = h.dy.alloc(T * sizeof(double)))) return rc;
+    if ((rc = h.dy.ensure(T * sizeof(double)))) return rc;
     HS_HIP(hipMemcpy(h.dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
     if (h.plan && hmmsort_plan_set_model(h.plan, tr, R, mu_inout, sigma)) h.drop_plan();
     bool keep = true;
@@ -800,8 +845,10 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
             continue;
         }
         const int64_t nlp = blocked_es ? generic_n_lp(h.plan->gen) : N;
-        if (!h.dstats.p && (rc = h.dstats.alloc(hmmsort_plan_stats_len(h.plan) * sizeof(double)))) return rc;
-        if (!h.dout.p && (rc = h.dout.alloc((K * N + 1 + nlp + S) * sizeof(double)))) return rc;
+        // sized for THIS plan: a cached slot's buffers may come from a plan of another engine or list
+        // (the slot key holds neither R nor the engine)
+        if ((rc = h.dstats.ensure(hmmsort_plan_stats_len(h.plan) * sizeof(double)))) return rc;
+        if ((rc = h.dout.ensure(hmmsort_plan_mstep_len(h.plan) * sizeof(double)))) return rc;
         if ((rc = hmmsort_plan_estep(h.plan, h.dy.as<double>(), h.dstats.as<double>(), nullptr))) return rc;
         if ((rc = hmmsort_plan_mstep(h.plan, h.dstats.as<double>(), h.dout.as<double>(), nullptr))) return rc;
         HS_HIP(hipDeviceSynchronize());
@@ -824,7 +871,8 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
         }
         // a wider warm-up changes the geometry: statistics buffer and plan are rebuilt
         h.drop_plan();
-        if (h.dstats.p) { (void)hipFree(h.dstats.p); h.dstats.p = nullptr; }
+        h.dstats.release();
+        h.dout.release();
         keep = false;
     }
     // generic engine: forward -> backward -> update with materialised alpha/beta, all on device

@@ -41,6 +41,8 @@ struct Options {
     int64_t escalate = 1;          // host-buffer entry points retry with a doubled warm-up
     int64_t plan_cache = 4;        // idle plans (+ device buffers) the host-buffer entry points keep
     int64_t strict_limit_mb = 0;   // largest back-pointer table the strict fallback may allocate (0 = what is free)
+    int64_t tie_scale = 1;         // test aid: multiplies the wave engine's near-tie threshold (more decisions flagged)
+    int64_t tie_debug = 0;         // test aids: 1 the resolver folds the exact prefix to the end, 2 resolver off
 };
 // process-wide options behind a mutex: entry points work on a snapshot taken when they start
 Options options_get();

@@ -44,6 +44,8 @@ struct WaveGeom {
     int64_t nseg;     // backtrace segments per channel
     int64_t own_lo, own_hi;  // time shard (hmmsort_plan_set_shard)
     int first, last;
+    double thr_scale;        // test aid: multiplier of the near-tie threshold (option "tie_scale")
+    int tie_debug;           // test aids (option "tie_debug"): 1 exact prefix folded to the end, 2 resolver off (flagged = unresolved)
 };
 
 // per-channel model constants (device table, wave-uniform scalar loads)
@@ -107,6 +109,15 @@ struct WaveDev {
     int64_t *diag = nullptr;          // 8
     double *trash = nullptr;          // 64 x 64 doubles: where idle lanes of a partial super-step store (branch-free stores)
     double *dbg = nullptr;            // 64 doubles: debug record of the first failing certificate
+    // exact near-tie resolver (wave_ties.hip)
+    int64_t *tie_cnt = nullptr;       // C x 8 counters (kTie* below)
+    int64_t *tie_list = nullptr;      // C x kTieCap flagged decisions on the decoded path: t * 32 + entry
+    int16_t *tie_walk = nullptr;      // C x kTieLanes x kTieWalk candidate paths (newest sample first)
+    double *tie_guess = nullptr;      // C x nblk approximate trellis value at every block start
+    double *tie_c = nullptr;          // C x nblk x 2 exact block increments for an even / odd start value
+    int32_t *tie_ok = nullptr;        // C x nblk block increments usable (one binade, path unchanged)
+    double *tie_v = nullptr;          // C x (nblk + 1) exact trellis values of the decoded path at block starts
+    int64_t tie_nblk = 0;
     int64_t bytes = 0;
     int nparts = 0, gparts = 0;
 };
@@ -268,6 +279,43 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// ---- exact near-tie resolver (wave_ties.hip) ------------------------------------------------------
+constexpr int kTieBlk = 512;                 // samples per block of the exact prefix
+constexpr int kTieCap = 4096;                // flagged decisions on the decoded path kept per channel
+constexpr int kTieWalk = 8192;               // longest candidate walk before it must have met the decoded path
+constexpr int kTieLanes = 64;                // candidates of one decision (junctions: silent + N ring exits; final arg-max: end states)
+// tie_cnt[ch * 8 + i]
+constexpr int kTieTrig = 0;                  // flagged decisions the backtrace met (trigger; may count one twice)
+constexpr int kTieListed = 1;                // flagged decisions on the final path (t >= 2)
+constexpr int kTieDone = 2;                  // decisions re-decided with the reference's arithmetic (incl. off-path ones)
+constexpr int kTieFlips = 3;                 // ... of which the back-pointer changed
+constexpr int kTieOpen = 4;                  // decisions left unresolved
+constexpr int kTieTail = 5;                  // final arg-max flagged
+constexpr int kTieLongest = 6;               // longest candidate walk
+constexpr int kTieSerial = 7;                // prefix blocks run serially
+
+// log-probability of the transition xp -> xc of a ring model (state ids 1-based), from the per-channel
+// table ctab = c00 | c0[N] | cend[N] | cx[N*N] | cint[N*L]
+__device__ __forceinline__ double wpath_lp(int N, int L, const double *__restrict__ ctab, int xp, int xc)
+{
+    if (xp == 1) return xc == 1 ? ctab[0] : ctab[1 + (xc - 2) / L];
+    const int a = (xp - 2) / L, k = (xp - 2) % L + 1;
+    if (k < L) return ctab[1 + 2 * N + N * N + a * L + k];
+    if (xc == 1) return ctab[1 + N + a];
+    return ctab[1 + 2 * N + a * N + (xc - 2) / L];
+}
+
+// Near-tie threshold of the Viterbi sweep: see wave_viterbi.hip.
+__device__ __forceinline__ double wave_thr(const WaveGeom &g, const WaveConst &K, const double *__restrict__ ysum, int ch)
+{
+    // largest magnitude the reference's trellis reaches: |sum_t (A - d^2/den + lp)| <= ...
+    const double T = (double)g.T;
+    const double s1 = ysum[2 * ch], s2 = ysum[2 * ch + 1];
+    const double sq = fmax((s2 - 2.0 * K.mean0 * s1) + T * K.mean0 * K.mean0, 0.0);
+    const double mmax = fabs(K.A) * T + sq / K.den + fabs(K.c00) * T + 1.0;
+    return (ldexp(16.0 * (double)(g.L + 2), ilogb(mmax) - 52) + 4.0e-9) * g.thr_scale;
+}
+
 // wave_engine.hip
 bool wave_supported(const HostModel &m, int64_t T, std::string *why);
 int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, int64_t block_req,
@@ -284,6 +332,9 @@ int wave_profile_read(WaveDev *r, hipStream_t st, std::vector<std::string> &name
 int wave_viterbi_sweep(WaveDev *r, const double *d_y, hipStream_t st);
 int wave_viterbi_post(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st);
 int wave_viterbi(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st);
+// wave_ties.hip
+int wave_tie_resolve(WaveDev *r, const double *d_y, int16_t *d_x, hipStream_t st);
+int wave_tie_stats(WaveDev *r, hipStream_t st, int64_t out[8]);
 // wave_estep.hip
 int wave_estep(WaveDev *r, const double *d_y, double *d_stats, hipStream_t st);
 int wave_mstep(WaveDev *r, const double *d_stats, double *d_out, hipStream_t st);

@@ -33,6 +33,7 @@ static int make_geometry(WaveGeom &g, int64_t T, int C, int N, int L, int64_t bl
 {
     g.T = T; g.C = C; g.N = N; g.L = L;
     g.own_lo = 0; g.own_hi = T; g.first = 1; g.last = 1;
+    { const Options o = options_get(); g.thr_scale = (double)o.tie_scale; g.tie_debug = (int)o.tie_debug; }
     g.W = std::min(L, 64);
     g.RB = (int)wround_up(L + g.W, 32);
     // warm-up: four ring lengths, at least 256 samples; with chains of thousands of samples this is
@@ -234,6 +235,14 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
     A(&r->diag, 8);
     A(&r->dbg, 64);
     A(&r->trash, 64 * 64);
+    r->tie_nblk = (T + kTieBlk - 1) / kTieBlk;
+    A(&r->tie_cnt, (int64_t)C * 8);
+    A(&r->tie_list, (int64_t)C * kTieCap);
+    A(&r->tie_walk, (int64_t)C * kTieLanes * kTieWalk);
+    A(&r->tie_guess, (int64_t)C * r->tie_nblk);
+    A(&r->tie_c, (int64_t)C * r->tie_nblk * 2);
+    A(&r->tie_ok, (int64_t)C * r->tie_nblk);
+    A(&r->tie_v, (int64_t)C * (r->tie_nblk + 1));
     if (!ok) { wave_destroy(r); return HMMSORT_ENOMEM; }
     if (getenv("HMMSORT_POISON")) {  // test aid: NaN bit patterns in everything a kernel might read unwritten
         (void)hipMemset(r->Rf, 0xFF, N * CT * 8);
@@ -253,6 +262,7 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
         (void)hipMemset(r->yhead, 0xFF, C * (N * L + 2) * 8);
     }
     if (hipMemset(r->diag, 0, 8 * sizeof(int64_t)) != hipSuccess ||
+        hipMemset(r->tie_cnt, 0, (size_t)C * 8 * sizeof(int64_t)) != hipSuccess ||
         hipMemset(r->vfail, 0, (nchT + 8) * sizeof(int32_t)) != hipSuccess) {
         wave_destroy(r);
         return HMMSORT_EHIP;
@@ -290,7 +300,8 @@ void wave_destroy(WaveDev *r)
     void *ptrs[] = {r->d_cst, r->d_mean, r->d_meanT, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->Rf, r->W2, r->virt, r->ysum,
                     r->psi, r->vpre, r->vend, r->vfail, r->bstate, r->redo, r->final_state, r->part, r->FA0,
                     r->FV, r->FREF, r->fpre, r->bpre, r->bown, r->rho, r->Zc, r->partS, r->partG, r->yhead,
-                    r->extra, r->pp, r->diag, r->dbg, r->trash};
+                    r->extra, r->pp, r->diag, r->dbg, r->trash, r->tie_cnt, r->tie_list, r->tie_walk, r->tie_guess,
+                    r->tie_c, r->tie_ok, r->tie_v};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);

@@ -22,10 +22,11 @@
 // differs from the reference's by rounding at the 1e-13 level (pre-summed ring scores, scan order,
 // per-chain offsets instead of the reference's O(t) cumulative sum, whose own rounding unit is
 // larger).  Every decision records whether its winner beat the runner-up by less than
-// thr = 16 sqrt(L+2) ulp(|T1|max) + 4e-9 (wave_thr below: many standard deviations of what the
-// reference's own rounding can move a difference between two paths) -- and the backtrace counts the
-// flagged decisions ON THE DECODED PATH in diag[7]: 0 means the path is the reference's bit for bit;
-// otherwise the host entry points decode with the strict engine.
+// thr = 16 (L+2) ulp(|T1|max) + 4e-9 (wave_thr, wave_common.h: the most the reference's own rounding can
+// move the difference between two paths that have been apart for up to 8 (L+2) steps).  The flagged
+// decisions ON THE DECODED PATH are then re-decided with the reference's own serial arithmetic
+// (wave_ties.hip: exact prefix T1 along the path, candidates replayed op for op, strict '>' in list
+// order); diag[7] counts the decisions that procedure could not settle (0 in every test).
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
@@ -42,23 +43,15 @@ struct WIn {
     double R[N];
 };
 
-// Near-tie threshold.  The reference compares candidates T1[k,t-1] + lp whose values have grown to
-// |T1| ~ t |A - 1/2| (ulp 1e-9 after 1e7 samples, 1.5e-8 after 1e8); two paths that separated d steps
-// ago carry independent rounding errors of d additions each, so the reference's own decision is noise
-// once the true margin is below sigma = ulp sqrt(d/6), d ~ 2(L+1) for one ring.  A decision is flagged
-// when its margin (in this engine's per-chain frame, rounding ~1e-13) is below
-//     thr = 16 sqrt(L+2) ulp(|T1|max) + 4e-9    (~27 sigma for one ring, 8 sigma for ten rings in a row),
-// the 4e-9 covering the tolerance of the chain-boundary certificate.
-__device__ __forceinline__ double wave_thr(const WaveGeom &g, const WaveConst &K, const double *__restrict__ ysum, int ch)
-{
-    // largest magnitude the reference's trellis reaches: |sum_t (A - d^2/den + lp)| <= ...
-    const double T = (double)g.T;
-    const double s1 = ysum[2 * ch], s2 = ysum[2 * ch + 1];
-    const double sq = fmax((s2 - 2.0 * K.mean0 * s1) + T * K.mean0 * K.mean0, 0.0);
-    const double mmax = fabs(K.A) * T + sq / K.den + fabs(K.c00) * T + 1.0;
-    return ldexp(16.0 * sqrt((double)(g.L + 2)), ilogb(mmax) - 52) + 4.0 * kVitTol;
-}
-
+// Near-tie threshold (wave_thr, wave_common.h).  The reference compares candidates T1[k,t-1] + lp whose
+// values have grown to |T1| ~ t |A - 1/2| (ulp 5e-10 after 1e7 samples, 4e-9 after 1e8).  Two candidate paths
+// that separated d steps ago share the value at their common ancestor exactly and then collect 2d roundings of
+// at most ulp/2 each, so the reference's computed margin differs from the exact one by at most (2d + 1) ulp.  A
+// decision is flagged when its margin (in this engine's per-chain frame, rounding ~1e-13) is below
+//     thr = 16 (L + 2) ulp(|T1|max) + 4e-9
+// -- the worst case for paths apart for up to 8 (L + 2) steps, the 4e-9 covering the tolerance of the
+// chain-boundary certificate.  Flagged decisions are not guessed: wave_ties.hip replays the reference's own
+// serial arithmetic for every flagged decision on the decoded path and re-decides it exactly.
 // UC ("uniform cx"): the log-probability of (b,L) -> (a,1) does not depend on b -- true for every
 // list the reference builds (types.jl:94-113: lp[a] + (N-2) lpz, accumulated in an order in which the
 // source ring only contributes an exact +0.0) and checked bitwise on the host (wave_set_model).  The
@@ -348,7 +341,7 @@ __global__ __launch_bounds__(64) void kw_vit_check(WaveGeom g, const double *__r
 __global__ __launch_bounds__(64) void kw_vit_tail(WaveGeom g, const WaveConst *__restrict__ cst,
                                                   const double *__restrict__ ysum,
                                                   const double *__restrict__ vend,
-                                                  int32_t *__restrict__ final_state, int64_t *__restrict__ diag)
+                                                  int32_t *__restrict__ final_state, int64_t *__restrict__ tie_cnt)
 {
     const int lane = threadIdx.x, ch = blockIdx.x;
     const int64_t SR = 1 + (int64_t)g.N * g.L;
@@ -371,7 +364,10 @@ __global__ __launch_bounds__(64) void kw_vit_tail(WaveGeom g, const WaveConst *_
     }
     if (lane == 0) {
         final_state[ch] = (bi >= S) ? 0 : bi;
-        if ((best - sec) < wave_thr(g, cst[ch], ysum, ch)) atomicAdd((unsigned long long *)&diag[7], 1ull);
+        if ((best - sec) < wave_thr(g, cst[ch], ysum, ch)) {   // wave_ties.hip re-decides it exactly
+            tie_cnt[ch * 8 + kTieTail] = 1;
+            atomicAdd((unsigned long long *)&tie_cnt[ch * 8 + kTieTrig], 1ull);
+        }
     }
 }
 
@@ -380,12 +376,13 @@ __global__ __launch_bounds__(64) void kw_vit_tail(WaveGeom g, const WaveConst *_
 // final state where that is the end of the data) and has merged with the true path by the time it
 // enters its segment (checked: kw_stitch_*).  psi is in natural time order, so a tile of 64 segments
 // x 64 samples is read with coalesced rows into LDS and walked column-wise; x leaves the same way.
-// Flagged (near-tie) junction decisions met inside the owned segment are counted in diag[7].
+// Flagged (near-tie) junction decisions met inside the owned segment are counted per channel (the trigger of
+// the exact resolver, wave_ties.hip).
 template <int N>
 __global__ __launch_bounds__(64) void kw_backtrace(WaveGeom g, const uint32_t *__restrict__ psi,
                                                    const int32_t *__restrict__ final_state,
                                                    int16_t *__restrict__ x, int32_t *__restrict__ bstate,
-                                                   int64_t *__restrict__ diag)
+                                                   int64_t *__restrict__ tie_cnt)
 {
     constexpr int EB = wpsi_bits_c(N), EPW = wpsi_epw_c(N), PW = wpsi_words_c(N);
     constexpr int TS = PW <= 2 ? 64 : 32;   // samples per tile (static LDS stays below 64 KB)
@@ -525,7 +522,7 @@ __global__ __launch_bounds__(64) void kw_backtrace(WaveGeom g, const uint32_t *_
     }
     if (active && hi_rel < te_rel) bstate[(int64_t)ch * g.nseg + sg] = bs;
     for (int o = 32; o > 0; o >>= 1) nflag += __shfl_xor(nflag, o);
-    if (lane == 0 && nflag) atomicAdd((unsigned long long *)&diag[7], (unsigned long long)nflag);
+    if (lane == 0 && nflag) atomicAdd((unsigned long long *)&tie_cnt[ch * 8 + kTieTrig], (unsigned long long)nflag);
 }
 
 __device__ __forceinline__ void wwalk_step(const WaveGeom &g, const uint32_t *__restrict__ pc, int64_t planePsi,
@@ -564,7 +561,8 @@ __global__ void kw_stitch_check(WaveGeom g, const int16_t *__restrict__ x, const
 // also takes the chains of consecutive failures this kernel leaves alone.
 __global__ __launch_bounds__(64) void kw_stitch_fix_par(WaveGeom g, const uint32_t *__restrict__ psi,
                                                         int16_t *__restrict__ x, int32_t *__restrict__ bstate,
-                                                        const int32_t *__restrict__ redo, int64_t *__restrict__ diag)
+                                                        const int32_t *__restrict__ redo, int64_t *__restrict__ diag,
+                                                        int64_t *__restrict__ tie_cnt)
 {
     extern __shared__ uint32_t shp[];                 // [PW][Bb + 1] psi of the segment and the sample after it | Bb ids
     const int lane = threadIdx.x, n = redo[0];
@@ -608,7 +606,7 @@ __global__ __launch_bounds__(64) void kw_stitch_fix_par(WaveGeom g, const uint32
             }
             bstate[(int64_t)ch * g.nseg + sg] = want;
             atomicAdd((unsigned long long *)&diag[1], 1ull);
-            if (nflag) atomicAdd((unsigned long long *)&diag[7], (unsigned long long)nflag);
+            if (nflag) atomicAdd((unsigned long long *)&tie_cnt[ch * 8 + kTieTrig], (unsigned long long)nflag);
         }
         __syncthreads();
         for (int i = lane; i < Bb; i += 64) xc[lo + i] = xs[i];
@@ -618,15 +616,16 @@ __global__ __launch_bounds__(64) void kw_stitch_fix_par(WaveGeom g, const uint32
 
 __global__ void kw_stitch_fix(WaveGeom g, const uint32_t *__restrict__ psi, int16_t *__restrict__ x,
                               int32_t *__restrict__ bstate, const int32_t *__restrict__ redo,
-                              int64_t *__restrict__ diag)
+                              int64_t *__restrict__ diag, int64_t *__restrict__ tie_cnt)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int n = redo[0];
     const int L = g.L, Bb = g.Bb;
     const int64_t planePsi = (int64_t)g.C * g.T;
-    int64_t fixes = 0, nflag = 0;
+    int64_t fixes = 0;
     for (int q = 0; q < n; q++) {
         const int ch = (int)(redo[1 + q] / g.nseg);
+        int64_t nflag = 0;
         int64_t sg = redo[1 + q] % g.nseg;
         const uint32_t *pc = psi + (int64_t)ch * g.T;
         int16_t *xc = x + (int64_t)ch * g.T;
@@ -646,9 +645,9 @@ __global__ void kw_stitch_fix(WaveGeom g, const uint32_t *__restrict__ psi, int1
             }
             sg--;  // did the first sample of segment sg change?  then segment sg-1 must be re-checked
         }
+        if (nflag) atomicAdd((unsigned long long *)&tie_cnt[ch * 8 + kTieTrig], (unsigned long long)nflag);
     }
     diag[1] += fixes;
-    diag[7] += nflag;
 }
 
 // The first decoded state, exactly as the reference finds it: x[0] = psi_1(x[1]) and psi_1 only sees
@@ -697,15 +696,6 @@ __global__ void kw_first_state(WaveGeom g, const WaveConst *__restrict__ cst, co
 
 // ll = sum_{t=1..T-1} T1[x_t, t]  (viterbi.jl:92-96) without the trellis:
 //   T1[x_t,t] = T1[x_0,0] + sum_{u=1..t} inc_u  =>  ll = (T-1) T1[x_0,0] + sum_u (T-u) inc_u.
-__device__ __forceinline__ double wpath_lp(int N, int L, const double *__restrict__ ctab, int xp, int xc)
-{
-    if (xp == 1) return xc == 1 ? ctab[0] : ctab[1 + (xc - 2) / L];
-    const int a = (xp - 2) / L, k = (xp - 2) % L + 1;
-    if (k < L) return ctab[1 + 2 * N + N * N + a * L + k];
-    if (xc == 1) return ctab[1 + N + a];
-    return ctab[1 + 2 * N + a * N + (xc - 2) / L];
-}
-
 __global__ __launch_bounds__(256) void kw_ll_partial(WaveGeom g, const WaveConst *__restrict__ cst,
                                                      const double *__restrict__ y, const int16_t *__restrict__ x,
                                                      const double *__restrict__ mean,
@@ -797,13 +787,14 @@ int wave_viterbi_post(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll,
         }
         { WPROF(r, "kw_vit_check", st);
           hipLaunchKernelGGL(kw_vit_check, dim3(nchT), dim3(64), 0, st, g, r->vpre, r->vend, r->vfail, r->diag, 1, r->dbg); }
+        HS_HIP(hipMemsetAsync(r->tie_cnt, 0, (size_t)g.C * 8 * sizeof(int64_t), st));
         { WPROF(r, "kw_vit_tail", st);
           hipLaunchKernelGGL(kw_vit_tail, dim3(g.C), dim3(64), 0, st, g, r->d_cst, r->ysum, r->vend, r->final_state,
-                             r->diag); }
+                             r->tie_cnt); }
         HS_HIP(hipMemsetAsync(r->redo, 0, sizeof(int32_t), st));
         { WPROF(r, "kw_backtrace", st);
           hipLaunchKernelGGL((kw_backtrace<N>), dim3((unsigned)((g.nseg + 63) / 64), g.C), dim3(64), 0, st, g, r->psi,
-                             r->final_state, d_x, r->bstate, r->diag); }
+                             r->final_state, d_x, r->bstate, r->tie_cnt); }
         HS_HIP(hipGetLastError());
         return HMMSORT_OK;
     });
@@ -816,13 +807,17 @@ int wave_viterbi_post(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll,
       // isolated failures in parallel, then a second check and the serial repair for what is left (chains of
       // consecutive failures, first samples that changed)
       const size_t ldsp = ((size_t)g.PW * (g.Bb + 1)) * sizeof(uint32_t) + (size_t)g.Bb * sizeof(int16_t) + 8;
-      hipLaunchKernelGGL(kw_stitch_fix_par, dim3(256), dim3(64), ldsp, st, g, r->psi, d_x, r->bstate, r->redo, r->diag);
+      hipLaunchKernelGGL(kw_stitch_fix_par, dim3(256), dim3(64), ldsp, st, g, r->psi, d_x, r->bstate, r->redo, r->diag,
+                         r->tie_cnt);
       HS_HIP(hipMemsetAsync(r->redo, 0, sizeof(int32_t), st));
       hipLaunchKernelGGL(kw_stitch_check, dim3((unsigned)((nsegT + 255) / 256)), dim3(256), 0, st, g, d_x, r->bstate,
                          r->redo);
-      hipLaunchKernelGGL(kw_stitch_fix, dim3(1), dim3(64), 0, st, g, r->psi, d_x, r->bstate, r->redo, r->diag); }
+      hipLaunchKernelGGL(kw_stitch_fix, dim3(1), dim3(64), 0, st, g, r->psi, d_x, r->bstate, r->redo, r->diag,
+                         r->tie_cnt); }
     { WPROF(r, "kw_first_state", st);
       hipLaunchKernelGGL(kw_first_state, dim3(g.C), dim3(64), 0, st, g, r->d_cst, d_y, r->d_mean, r->d_ctab, d_x); }
+    // flagged near-ties on the decoded path: re-decided with the reference's own arithmetic (no-ops otherwise)
+    if ((rc = wave_tie_resolve(r, d_y, d_x, st))) return rc;
     { WPROF(r, "kw_ll_partial", st);
       hipLaunchKernelGGL(kw_ll_partial, dim3(r->nparts, g.C), dim3(256), 0, st, g, r->d_cst, d_y, d_x, r->d_mean,
                          r->d_ctab, r->part); }

@@ -104,10 +104,11 @@ class Plan:
         return int(lib().hmmsort_plan_stats_len(self._h))
 
     def mstep_len(self):
-        """[mu (K x N) | sigma | xb[2:end] | pp (S)]: xb has one entry per transition leaving state 1
-        (baumwelch.jl:226), N + 1 of them without overlaps"""
-        nsrc1 = int((np.asarray(self.lA.transitions["src"]) == 1).sum())
-        return self.K * self.N + 1 + (nsrc1 - 1) + self.S
+        """doubles per channel of the M-step output [mu (K x N) | sigma | xb[2:end] | pp (S)], as the library
+        writes them (hmmsort_plan_mstep_len): N entry log-probabilities for wave/ring plans whatever the
+        list has dropped (types.jl:121), one per transition leaving state 1 but the first otherwise
+        (baumwelch.jl:226,264)"""
+        return int(lib().hmmsort_plan_mstep_len(self._h))
 
     def estep(self, d_y, d_stats, stream=0):
         check(lib().hmmsort_plan_estep(self._h, _dptr(d_y), _dptr(d_stats), C.c_void_p(stream)))
@@ -128,6 +129,13 @@ class Plan:
         for i in (2, 4, 6):  # largest boundary errors travel as double bit patterns
             out[i] = struct.unpack("<d", struct.pack("<q", out[i]))[0]
         return out
+
+    def tie_stats(self, stream=0):
+        """what the exact near-tie resolver did in the last decode (hmmsort_plan_tie_stats)"""
+        d = (C.c_int64 * 8)()
+        check(lib().hmmsort_plan_tie_stats(self._h, C.c_void_p(stream), d))
+        return dict(zip(("trigger", "flagged", "decided", "flips", "unresolved", "tail", "longest_walk",
+                         "serial_blocks"), list(d)))
 
     def reconstruct(self, d_x, d_y_out, stream=0):
         """reconstruct_signal of a decoded path, device to device (T doubles)"""

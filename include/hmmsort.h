@@ -235,6 +235,10 @@ int hmmsort_plan_set_shard(hmmsort_plan *plan, int64_t own_lo, int64_t own_hi, i
  * (overlap models) take the same three calls estep / all-reduce / mstep; their statistics vector is
  * [G0 (S) | G1 (S) | X | Gamma0 | sum y^2]. */
 int hmmsort_plan_mstep(hmmsort_plan *plan, const double *d_stats, double *d_out, void *stream);
+/* doubles hmmsort_plan_mstep writes PER CHANNEL: K*N + 1 + n_lp + S, n_lp = N for wave/ring plans (also when
+ * the list has lost a vanished template's entry transitions, types.jl:121: its slot stays, value -Inf or the
+ * re-estimate), (#transitions leaving state 1) - 1 for the blocked engine (baumwelch.jl:226,264). */
+int64_t hmmsort_plan_mstep_len(const hmmsort_plan *plan);
 /* diagnostics of the last time-parallel call on this plan (synchronises the stream):
  * diag[0] = chain boundaries whose Viterbi warm-up missed the certificate (the warm-up's boundary
  *           scores must equal the previous chain's up to one constant; ring engine 1e-6 on the
@@ -251,10 +255,21 @@ int hmmsort_plan_mstep(hmmsort_plan *plan, const double *d_stats, double *d_out,
  *           granularity of the reference's trellis at that point (near-ties, e.g. duplicate
  *           templates): the blocks' additive frames may then break a tie the reference breaks by
  *           list order; hmmsort_viterbi re-decodes such signals with the strict engine.
- *           Wave engine: diag[7] = junction decisions ON the decoded path whose margin is below
- *           16 sqrt(L+2) ulp(|T1|max) + 4e-9 (the reference's own rounding noise at the magnitude its
- *           trellis reaches on this signal); same consequence. */
+ *           Wave engine: junction decisions whose margin is below 16 (L+2) ulp(|T1|max) + 4e-9 (the most the
+ *           reference's own rounding can move a difference at the magnitude its trellis reaches on this
+ *           signal) are flagged, and the flagged ones ON the decoded path are re-decided on device with the
+ *           reference's serial arithmetic (hmmsort_plan_tie_stats); diag[7] = decisions that could NOT be
+ *           settled that way (0 on every signal seen; same consequence as above otherwise). */
 int hmmsort_plan_diagnostics(hmmsort_plan *plan, void *stream, int64_t diag[8]);
+
+/* Wave engine: what the exact near-tie resolver did in the last decode (synchronises the stream), summed
+ * over the channels: out[0] flagged junction decisions the backtrace met (trigger), out[1] flagged decisions
+ * on the final path, out[2] decisions re-decided with the reference's serial arithmetic (viterbi.jl:74-84;
+ * includes flagged decisions off the path that a candidate's own history ran through), out[3] decisions
+ * whose back-pointer changed, out[4] decisions left unresolved (== diag[7]), out[5] channels whose final
+ * arg-max (viterbi.jl:90) was flagged, out[6] longest candidate walk in samples (max), out[7] blocks of the
+ * exact prefix that were folded serially.  Zeros for other engines. */
+int hmmsort_plan_tie_stats(hmmsort_plan *plan, void *stream, int64_t out[8]);
 
 /* reconstruct_signal (reconstruction.jl:1-10) and unroll_mlseq (extraction.jl:4-13) of a decoded
  * path in device memory into device buffers (T doubles / N x T Int16, column-major); the model

@@ -136,11 +136,13 @@ def test_int16_samples_are_widened_on_the_device(H):
 
 
 def test_strict_fallback_that_does_not_fit_returns_the_time_parallel_path(H):
-    # duplicate templates: every spike is a tie the reference breaks by its own rounding; the wave engine
-    # flags those decisions (diag[7]) and hmmsort_viterbi re-decodes with the strict engine -- unless the strict
-    # sweep's S x T back-pointer table does not fit (0.8 TB at config 5's 10^8 samples; here: a 1 MB limit).
-    # Then the time-parallel path is returned, last_escalations < 0 says how many decisions are open, and the
-    # path is as likely as the strict one (equal ll).
+    # duplicate templates: every spike is a tie the reference breaks by its own rounding.  The wave engine
+    # flags those decisions and re-decides them with the reference's serial arithmetic (wave_ties.hip): the
+    # path is the strict engine's without any escalation.  With the resolver switched off (test aid
+    # tie_debug = 2: every flagged decision stays open, diag[7] > 0) hmmsort_viterbi re-decodes with the strict
+    # engine -- unless the strict sweep's S x T back-pointer table does not fit (here: a 1 MB limit); then the
+    # time-parallel path is returned, last_escalations < 0 says how many decisions are open, and the path is
+    # as likely as the strict one (equal ll).
     import warnings
     K, N, T = 40, 2, 200_000
     t1 = H.create_spike_template(K, 3.0, 0.8, 0.2)
@@ -148,10 +150,20 @@ def test_strict_fallback_that_does_not_fit_returns_the_time_parallel_path(H):
     pp = [0.004, 0.004]
     sm = H.StateMatrix.create(N, K, np.log(pp), False)
     y = H.create_signal(T, 0.3, pp, temps, seed=3)
-    x0, ll0 = H.viterbi(y, sm, temps, 0.3)                       # AUTO: ties -> strict engine
-    assert H.get_option("last_escalations") >= 1
-    H.set_option("strict_limit_mb", 1)
+    H.set_option("engine", H.ENGINE_STRICT)
+    xs, lls = H.viterbi(y, sm, temps, 0.3)
+    H.set_option("engine", H.ENGINE_AUTO)
+    H.shutdown()
+    xr, llr = H.viterbi(y, sm, temps, 0.3)                       # AUTO: wave engine + exact resolver
+    assert H.get_option("last_escalations") == 0
+    assert np.array_equal(xr, xs) and abs(llr - lls) <= 1e-9 * abs(lls)
+    H.shutdown()
+    H.set_option("tie_debug", 2)
     try:
+        x0, ll0 = H.viterbi(y, sm, temps, 0.3)                   # resolver off: ties -> strict engine
+        assert H.get_option("last_escalations") >= 1
+        assert np.array_equal(x0, xs)
+        H.set_option("strict_limit_mb", 1)
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
             x1, ll1 = H.viterbi(y, sm, temps, 0.3)
@@ -159,6 +171,7 @@ def test_strict_fallback_that_does_not_fit_returns_the_time_parallel_path(H):
         assert open_ties >= 1 and len(w) == 1 and "near-tie" in str(w[0].message)
     finally:
         H.set_option("strict_limit_mb", 0)
+        H.set_option("tie_debug", 0)
         H.shutdown()
     assert abs(ll1 - ll0) <= 1e-9 * abs(ll0)
     # the two paths agree except for which of the twin rings carries a spike
