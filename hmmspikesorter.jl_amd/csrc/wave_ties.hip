@@ -241,25 +241,128 @@ struct TieRun {
     double *inc;           // LDS: 128 doubles (a | q of 64 samples)
 };
 
+// index into ctab of the transition xp -> xc (wpath_lp without the branches around the load)
+__device__ __forceinline__ int tie_lp_index(int N, int L, int xp, int xc)
+{
+    const int a = (xp - 2) / L, k = (xp - 2) - a * L + 1, b = (xc - 2) / L;
+    const int from_silent = xc == 1 ? 0 : 1 + b;
+    const int from_ring = k < L ? 1 + 2 * N + N * N + a * L + k : (xc == 1 ? 1 + N + a : 1 + 2 * N + a * N + b);
+    return xp == 1 ? from_silent : from_ring;
+}
+
 // serial fold over samples (from, to] from v (the value at `from`), all lanes in step: the lanes fetch the
-// increments of 64 samples in parallel, then every lane adds them in order (same value in every lane)
+// increments of 64 samples in parallel (the next 64 while the current ones are added), then every lane adds
+// them in order (same value in every lane)
 __device__ double tie_fold(const TieChan &c, const TieRun &R, double v, int64_t from, int64_t to, int lane)
 {
-    for (int64_t u0 = from + 1; u0 <= to; u0 += 64) {
+    if (to <= from) return v;
+    auto fetch = [&](int64_t u0, double &a, double &q) {
         const int64_t u = u0 + lane;
-        double a = 0.0, q = 0.0;
-        if (u <= to) {
-            const int xp = c.x[u - 1], xn = c.x[u];
-            a = wpath_lp(c.N, c.L, c.ctab, xp, xn);
-            q = tie_q(c, xn, u);
-        }
+        const int64_t uc = u <= to ? u : to;
+        const int xp = c.x[uc - 1], xn = c.x[uc];
+        const double av = c.ctab[tie_lp_index(c.N, c.L, xp, xn)];
+        const double dd = c.y[uc] - c.mean[xn - 1];
+        const double qv = c.A - (dd * dd) / c.den;
+        a = u <= to ? av : 0.0;
+        q = u <= to ? qv : 0.0;
+    };
+    double a, q;
+    fetch(from + 1, a, q);
+    for (int64_t u0 = from + 1; u0 <= to; u0 += 64) {
         R.inc[lane] = a; R.inc[64 + lane] = q;
         __syncthreads();
-        const int n = (to - u0 + 1) < 64 ? (int)(to - u0 + 1) : 64;
-        for (int i = 0; i < n; i++) v = (v + R.inc[i]) + R.inc[64 + i];
+        if (u0 + 64 <= to) fetch(u0 + 64, a, q);
+        // samples past `to` were fetched as zeros: v + 0.0 + 0.0 is v
+#pragma unroll 16
+        for (int i = 0; i < 64; i++) v = (v + R.inc[i]) + R.inc[64 + i];
         __syncthreads();
     }
     return v;
+}
+
+// Advance the exact prefix to block start bt.  64 blocks at a time: a block is the map
+// v -> v + c[parity(v/U)] with parity(v'/U) = parity(v/U) xor parity(c/U), and such maps compose, so the start
+// values of 64 consecutive blocks come from one lane scan over (increment, parity) pairs for both start
+// parities.  Every lane then checks that ITS start value lies in the binade its increments were computed in
+// and next to the approximate value they were computed from; the blocks before the first lane that fails are
+// accepted, that block is folded serially.  Increments are multiples of U below 2^53 U (|v| >= 2^16 here), so
+// every sum is exact.
+__device__ void tie_chain(const TieChan &c, TieRun &R, int64_t bt, int lane)
+{
+    double v = R.vcur;
+    int64_t b = R.valid;
+    // the records of the NEXT 64 blocks are fetched while the current 64 are scanned
+    double ngv = 0.0, nc0 = 0.0, nc1 = 0.0;
+    int nok = 0;
+    int64_t nbase = -1;
+    auto fetch = [&](int64_t base) {
+        const int64_t bi = (base + lane) < R.nblk ? (base + lane) : (R.nblk - 1);
+        ngv = R.guess[bi]; nc0 = R.tc[2 * bi]; nc1 = R.tc[2 * bi + 1]; nok = R.tok[bi];
+        nbase = base;
+    };
+    while (b < bt) {
+        const int nb = (bt - b) < 64 ? (int)(bt - b) : 64;
+        const bool in = lane < nb;
+        if (nbase != b) fetch(b);
+        const double gv = ngv, c0 = nc0, c1 = nc1;
+        const int okb = nok;
+        if (b + 64 < bt) fetch(b + 64);
+        const bool vfin = v == v && fabs(v) < INFINITY && v != 0.0;
+        const int ev = vfin ? ilogb(fabs(v)) : 0;
+        const bool lane_ok = !in || (okb != 0 && gv == gv && gv != 0.0 && fabs(gv) < INFINITY &&
+                                     ilogb(fabs(gv)) == ev && ((gv < 0) == (v < 0)));
+        const unsigned long long bad = __ballot(!lane_ok);
+        const int nfast = bad ? __ffsll((long long)bad) - 1 : nb;
+        int ngood = 0;
+        double inc_incl = 0.0;
+        if (vfin && ev >= 16 && nfast > 0) {
+            const double sU = ldexp(1.0, 52 - ev);   // 1 / U
+            double C0 = lane < nfast ? c0 : 0.0, C1 = lane < nfast ? c1 : 0.0;
+            int P0 = (int)((long long)(C0 * sU) & 1ll), P1 = 1 ^ (int)((long long)(C1 * sU) & 1ll);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double aC0 = __shfl_up(C0, d), aC1 = __shfl_up(C1, d);
+                const int aP0 = __shfl_up(P0, d), aP1 = __shfl_up(P1, d);
+                if (lane >= d) {
+                    const double n0 = aC0 + (aP0 ? C1 : C0), n1 = aC1 + (aP1 ? C1 : C0);
+                    const int q0 = aP0 ? P1 : P0, q1 = aP1 ? P1 : P0;
+                    C0 = n0; C1 = n1; P0 = q0; P1 = q1;
+                }
+            }
+            inc_incl = (__double_as_longlong(v) & 1ll) ? C1 : C0;
+            double inc_excl = __shfl_up(inc_incl, 1);
+            if (lane == 0) inc_excl = 0.0;
+            const double vi = v + inc_excl;          // exact value at the start of block b + lane
+            const bool good = lane >= nfast || (ilogb(fabs(vi)) == ev && ((vi < 0) == (v < 0)) &&
+                                                fabs(vi - gv) < 0.5 * kTieMargin);
+            const unsigned long long nb2 = __ballot(!good);
+            ngood = nb2 ? __ffsll((long long)nb2) - 1 : nfast;
+        }
+        if (ngood > 0) {
+            const double ve = v + inc_incl;          // value at the END of block b + lane
+            if (lane < ngood) R.tv[b + lane + 1] = ve;
+            v = wave_bcast(ve, ngood - 1);
+            b += ngood;
+            continue;
+        }
+        {   // one block the slow way: per-block increment when its start value fits, else the serial fold
+            const double gv0 = wave_bcast(gv, 0), t0 = wave_bcast(c0, 0), t1 = wave_bcast(c1, 0);
+            const int ok0 = __shfl(okb, 0);
+            bool fast = ok0 != 0 && vfin && gv0 != 0.0 && gv0 == gv0 && fabs(gv0) < INFINITY;
+            if (fast) fast = ilogb(fabs(gv0)) == ev && ((v < 0) == (gv0 < 0)) && fabs(v - gv0) < 0.5 * kTieMargin;
+            if (fast) {
+                v = v + ((__double_as_longlong(v) & 1ll) ? t1 : t0);
+            } else {
+                const int64_t to = ((b + 1) * kTieBlk) < (c.T - 1) ? ((b + 1) * kTieBlk) : (c.T - 1);
+                v = tie_fold(c, R, v, b * kTieBlk, to, lane);
+                if (lane == 0) R.cnt[kTieSerial] += 1;
+            }
+            if (lane == 0) R.tv[b + 1] = v;
+            b += 1;
+        }
+    }
+    R.valid = bt;
+    R.vcur = v;
 }
 
 // exact T1[x_u, u] of the decoded path
@@ -270,23 +373,8 @@ __device__ double tie_exact(const TieChan &c, TieRun &R, int64_t u, int lane)
         __threadfence();
         return tie_fold(c, R, R.tv[bt], bt * kTieBlk, u, lane);
     }
-    double v = R.vcur;
-    for (int64_t b = R.valid; b < bt; b++) {
-        const double gv = R.guess[b];
-        bool fast = R.tok[b] != 0 && v == v && fabs(v) < INFINITY && v != 0.0 && gv != 0.0;
-        if (fast) fast = ilogb(fabs(v)) == ilogb(fabs(gv)) && ((v < 0) == (gv < 0)) && fabs(v - gv) < 0.5 * kTieMargin;
-        if (fast) {
-            v = v + R.tc[2 * b + (int)(__double_as_longlong(v) & 1ll)];
-        } else {
-            const int64_t to = ((b + 1) * kTieBlk) < (c.T - 1) ? ((b + 1) * kTieBlk) : (c.T - 1);
-            v = tie_fold(c, R, v, b * kTieBlk, to, lane);
-            if (lane == 0) R.cnt[kTieSerial] += 1;
-        }
-        if (lane == 0) R.tv[b + 1] = v;
-    }
-    R.valid = bt;
-    R.vcur = v;
-    return tie_fold(c, R, v, bt * kTieBlk, u, lane);
+    if (bt > R.valid) tie_chain(c, R, bt, lane);
+    return tie_fold(c, R, R.vcur, bt * kTieBlk, u, lane);
 }
 
 struct TieWalk {
@@ -297,24 +385,31 @@ struct TieWalk {
     int64_t ft;
 };
 
+// eight samples of the decoded path per round trip (the loads do not depend on the walk's state)
 __device__ TieWalk tie_walk(const TieChan &c, int16_t *scr, int s, int64_t tau)
 {
     TieWalk w;
     w.n = 0; w.status = 0; w.fe = 0; w.ft = 0; w.u = 0;
     for (;;) {
-        if (c.x[tau] == s) { w.u = tau; return w; }
-        if (w.n >= kTieWalk) { w.status = 2; return w; }
-        scr[w.n++] = (int16_t)s;
-        if (tau == 0) { w.u = -1; return w; }
-        const int e = tie_entry_of(c, s);
-        if (e < 0) {
-            s = s - 1;
-        } else {
-            const uint32_t ent = tie_psi_get(c, e, tau);
-            if (ent >> (c.EB - 1)) { w.status = 1; w.fe = e; w.ft = tau; return w; }
-            s = tie_pred_state(c, (int)ent);
+        int xb[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const int64_t tj = tau - j; xb[j] = c.x[tj > 0 ? tj : 0]; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (xb[j] == s) { w.u = tau; return w; }
+            if (w.n >= kTieWalk) { w.status = 2; return w; }
+            scr[w.n++] = (int16_t)s;
+            if (tau == 0) { w.u = -1; return w; }
+            const int e = tie_entry_of(c, s);
+            if (e < 0) {
+                s = s - 1;
+            } else {
+                const uint32_t ent = tie_psi_get(c, e, tau);
+                if (ent >> (c.EB - 1)) { w.status = 1; w.fe = e; w.ft = tau; return w; }
+                s = tie_pred_state(c, (int)ent);
+            }
+            tau--;
         }
-        tau--;
     }
 }
 
@@ -358,10 +453,31 @@ __device__ int tie_eval(const TieChan &c, TieRun &R, int lane, bool valid, int s
         int64_t tau;
         if (umin >= 0) { v = V; sp = c.x[umin]; tau = umin + 1; }
         else { sp = (w.u < 0) ? (int)scr[w.n - 1] : (int)c.x[0]; v = tie_base(c, sp); tau = 1; }
-        for (; tau <= t - 1; tau++) {
-            const int sc = (tau <= w.u) ? (int)c.x[tau] : (int)scr[t - 1 - tau];
-            v = (v + wpath_lp(c.N, c.L, c.ctab, sp, sc)) + tie_q(c, sc, tau);
-            sp = sc;
+        // eight steps per round trip: states, then their means / samples / log-probabilities, then the adds
+        for (; tau <= t - 1; tau += 8) {
+            int sc[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int64_t tj = (tau + j) <= (t - 1) ? (tau + j) : (t - 1);
+                const int64_t si = t - 1 - tj;
+                const int xs = c.x[tj], ws = scr[si < w.n ? si : 0];
+                sc[j] = (tj <= w.u) ? xs : ws;
+            }
+            double a[8], q[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int64_t tj = (tau + j) <= (t - 1) ? (tau + j) : (t - 1);
+                const int spj = j == 0 ? sp : sc[j - 1];
+                const double av = c.ctab[tie_lp_index(c.N, c.L, spj, sc[j])];
+                const double dd = c.y[tj] - c.mean[sc[j] - 1];
+                const double qv = c.A - (dd * dd) / c.den;
+                const bool live = (tau + j) <= (t - 1);
+                a[j] = live ? av : 0.0;
+                q[j] = live ? qv : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) v = (v + a[j]) + q[j];
+            sp = sc[7];
         }
         tt = addlp ? v + lpC : v;
     }

@@ -145,7 +145,7 @@ def test_config3_ten_em_iterations_at_10M(H):
     sm_r, mu_r, sig_r, hist_r = device_loop(H, y, sm1, mu1, 0.45, 10)
     assert np.abs(mu_r - temps).max() < 0.02 and abs(sig_r - 0.3) < 2e-3
     lp_r = sm_r.transitions["lp"][1:1 + N]
-    assert np.allclose(np.exp(lp_r) / np.exp(sm_r.transitions["lp"][0] / N) if False else np.exp(lp_r), pp, rtol=0.08)
+    assert np.allclose(np.exp(lp_r), pp, rtol=0.08)
 
 
 def test_reference_baum_welch_testset(H):

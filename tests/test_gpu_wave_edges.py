@@ -68,6 +68,54 @@ def test_signal_ending_and_starting_inside_a_spike(O, H):
     assert np.allclose(smn.pi, opp, rtol=1e-8, atol=1e-8)
 
 
+def _per_source_list(H, sm, N, K, rng):
+    """A ring-model list whose exit->entry log-probabilities (b,L) -> (a,1) depend on the SOURCE ring b: the
+    wave engine's `uniform cx` shortcut (one top-3 over the ring exits serves every junction) does not apply
+    and the kernels take their O(N^2) junction code (kw_vit/kw_fwd/kw_bwd with UC = false).  Lists built by
+    types.jl:94-113 reach that code only when the neuron-order sums differ in the last bit between sources."""
+    L = K - 1
+    tr = sm.transitions.copy()
+    n = 0
+    for i in range(len(tr)):
+        s, d = int(tr["src"][i]), int(tr["dst"][i])
+        if s > 1 and d > 1 and (s - 2) % L == L - 1 and (d - 2) % L == 0:
+            tr["lp"][i] += rng.uniform(-0.7, 0.7)
+            n += 1
+    assert n == N * (N - 1)
+    return H.StateMatrix(sm.states, tr, sm.pi, sm.K, sm.N, sm.nstates, False)
+
+
+@pytest.mark.parametrize("N,K,T,seed", [(4, 60, 150_000, 1), (3, 30, 40_000, 2), (8, 40, 60_000, 3), (12, 24, 50_000, 4)])
+def test_exit_to_entry_values_that_depend_on_the_source_ring(O, H, N, K, T, seed):
+    rng = np.random.default_rng(seed)
+    base = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)]
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, base[i % 4][0] * (1 + 0.15 * (i // 4)),
+                                                                 base[i % 4][1] + 0.04 * (i // 4), base[i % 4][2])
+                                        for i in range(N)], 1))
+    # busy enough that spikes follow each other directly (the exit -> entry transitions are on the paths)
+    pp = rng.uniform(0.004, 0.012, N) * min(1.0, 4.0 / N)
+    y = H.create_signal(T, 0.3, pp, temps, seed=seed)
+    sm = _per_source_list(H, H.StateMatrix.create(N, K, np.log(pp), False), N, K, rng)
+    osm = to_oracle_sm(O, sm)
+    x, ll = H.viterbi(y, sm, temps, 0.3)
+    xo, llo = O.viterbi(y, osm, temps, 0.3)
+    # the paths do use ring -> ring transitions
+    L = K - 1
+    direct = np.count_nonzero((xo[:-1] > 1) & ((xo[:-1] - 2) % L == L - 1) & (xo[1:] > 1))
+    assert direct > 3, direct
+    assert np.array_equal(x, xo), int(np.count_nonzero(x != xo))
+    assert abs(ll - llo) <= 1e-9 * abs(llo)
+    mu = np.asfortranarray(temps * rng.uniform(0.85, 1.1, N)[None, :])
+    mu[0, :] = 0
+    smn, mun, sgn = H.train_step(y, sm, mu.copy(order="F"), 0.4)
+    osmn, omu, osig, olp, opp = O.train_step(y, osm, mu.copy(order="F"), 0.4)
+    assert H.get_option("last_escalations") == 0
+    assert np.allclose(mun, omu, rtol=1e-8, atol=1e-11), np.abs(mun - omu).max()
+    assert abs(sgn - osig) <= 1e-8 * osig
+    assert np.allclose(smn.transitions["lp"], osmn.val, rtol=1e-8)
+    assert np.allclose(smn.pi, opp, rtol=1e-8, atol=1e-8)
+
+
 def test_non_finite_samples_do_not_hang(H):
     # garbage in, garbage out -- but every kernel terminates and the call returns
     K, N, T = 30, 2, 20_000
