@@ -72,11 +72,12 @@ def kernel_sources_hash():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(T, block):
+def measured_traffic(T, block, N=4, K=60, channels=1):
     """Per-kernel HBM bytes per launch from a committed rocprofv3 PMC summary (profiles/<tag>_summary.json:
     separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 x2 read correction) -- but only
     of a summary taken with EXACTLY the kernel sources this process runs (_meta.kernel_sources) on the
-    same workload; otherwise None, and the line says so."""
+    same workload (samples per channel, chain length, model shape, channels per plan); otherwise None, and
+    the line says so."""
     import glob
     want = kernel_sources_hash()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
@@ -85,7 +86,8 @@ def measured_traffic(T, block):
         except Exception:
             continue
         meta = d.get("_meta", {})
-        if meta.get("kernel_sources") == want and meta.get("samples") == T and meta.get("block") == block:
+        if (meta.get("kernel_sources") == want and meta.get("samples") == T and meta.get("block") == block and
+                meta.get("neurons", 4) == N and meta.get("states", 60) == K and meta.get("channels", 1) == channels):
             measured_traffic.raw = d
             return {k: v["hbm_read_bytes"] + v["hbm_write_bytes"] for k, v in d.items() if k != "_meta"}, \
                 os.path.basename(path)
@@ -95,7 +97,194 @@ def measured_traffic(T, block):
 measured_traffic.raw = None
 
 
-def cpu_baseline(H, N, K, temps, pp, sigma):
+def shape_roofline(plan, info, N, K, T, channels, step_s, stream, profiled_step):
+    """roofline block of one model shape: per-kernel HIP-event times of `profiled_step` (decode and E-step as
+    separate calls, like the headline's profiling pass), the dominant kernel's HBM bytes (rocprofv3 counters of a
+    committed summary of these very sources and this workload, else the bytes the kernel moves by design) over
+    its launch time, and the same over the whole step."""
+    plan.profile(True)
+    profiled_step()
+    prof = plan.profile_read(stream)
+    plan.profile(False)
+    ksum = {k: v[0] / v[1] for k, v in prof.items()}
+    per_step = {k: v[0] for k, v in prof.items()}
+    dom = max(per_step, key=per_step.get)
+    counters, src = measured_traffic(T, info["block"], N, K, channels)
+    model = {k: (engine_bytes(k, N, T, info) or 0.0) * channels for k in ksum}
+    dom_counter = counters.get(dom) if counters else None
+    dom_bytes = dom_counter if dom_counter is not None else model.get(dom)
+    bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
+    achieved = dom_bytes / (ksum[dom] * 1e-3) / 1e9 if dom_bytes else None
+    if dom == "kw_gsum":   # Toeplitz product on the fp64 matrix cores: 2 flop x N L T useful flops (G1 only; G2 through W2)
+        bound, peak, unit = "mfma", 78.6, "TFLOP/s"
+        achieved = 2.0 * N * (K - 1) * T * channels / (ksum[dom] * 1e-3) / 1e12
+    step_counters = sum(counters.get(k, 0.0) * prof[k][1] for k in ksum) if counters else None
+    step_model = sum(model.values())
+    return {"bound": bound, "kernel": dom, "achieved": achieved, "peak": peak, "unit": unit,
+            "frac": (achieved / peak) if achieved else None, "traffic": dom_counter,
+            "traffic_source": src if dom_counter is not None else
+            "none committed for these kernel sources and this workload: design bytes",
+            "avg_launch_ms": ksum[dom],
+            "kernel_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+            "step": {"ms": step_s * 1e3, "bytes_model": step_model, "bytes_counters": step_counters,
+                     "frac": (step_counters or step_model) / step_s / 1e9 / HBM_PEAK_GBS}}
+
+
+def bench_model(H, N, K):
+    """the model/signal family of this benchmark (SURVEY 8d synthetic inputs scaled to N templates, K states)"""
+    base = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)]
+    amps = [(base[i % 4][0] * (1 + 0.13 * (i // 4)), base[i % 4][1] + 0.03 * (i // 4), base[i % 4][2])
+            for i in range(N)]
+    pp = [[0.003, 0.001, 0.002, 0.0015][i % 4] * (60.0 / K) for i in range(N)]
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, *a) for a in amps], 1))
+    return temps, pp, H.StateMatrix.create(N, K, np.log(pp), False)
+
+
+def run_config45(args, torch, H, dist, world, rank, dev):
+    """BASELINE configs 4 and 5: many independent channels (the reference sorts one channel per call with its
+    own model, src/hmmsort.jl:79-83), dealt round-robin over the ranks (dist.shard_channels); a rank sweeps its
+    channels `batch` at a time through ONE batched plan.  No data-path collective; --pooled sums the
+    statistics of all channels (one SUM all-reduce per step over RCCL) before the M-step -- pooled templates
+    are an extension the reference lacks.  One step = decode + E-step + M-step finish of every channel once;
+    value = all channels' samples / the slowest rank's time.  The total work is fixed: strong scaling."""
+    cfg = args.config
+    N, K = (8, 128) if cfg == 4 else (16, 256)
+    if args.neurons != 4 or args.states != 60:
+        N, K = args.neurons, args.states
+    T = args.samples if args.samples != 10_000_000 or cfg == 4 else 100_000_000
+    total = args.total_channels or (64 if cfg == 4 else 8)
+    batch = args.batch or (8 if cfg == 4 else 1)
+    sigma = 0.3
+    temps, pp, sm = bench_model(H, N, K)
+    S = sm.nstates
+    mine = H.dist.shard_channels(total, rank, world)
+    H.set_option("engine", args.engine)
+    H.set_option("block", args.block)
+    H.set_option("halo", args.halo)
+    stream = torch.cuda.current_stream().cuda_stream
+    groups = [mine[i:i + batch] for i in range(0, len(mine), batch)]
+    plans = {}
+
+    def plan_for(n):
+        if n not in plans:
+            plans[n] = H.Plan.batched(T, [sm] * n, [temps] * n, [sigma] * n)
+        return plans[n]
+
+    # signals stay resident in HBM (channel-major per group); per-channel seeds
+    ys, xs, lls, sts, outs = [], [], [], [], []
+    for grp in groups:
+        yy = torch.empty((len(grp), T), dtype=torch.float64, device=dev)
+        for i, ch in enumerate(grp):
+            yy[i] = torch.from_numpy(H.create_signal(T, sigma, pp, temps, seed=1234 + ch)).to(dev)
+        pl = plan_for(len(grp))
+        ys.append(yy)
+        xs.append(torch.zeros((len(grp), T), dtype=torch.int16, device=dev))
+        lls.append(torch.zeros(len(grp), dtype=torch.float64, device=dev))
+        sts.append(torch.zeros((len(grp), pl.stats_len()), dtype=torch.float64, device=dev))
+        outs.append(torch.zeros((len(grp), pl.mstep_len()), dtype=torch.float64, device=dev))
+    slen = plan_for(batch).stats_len() if groups else 0
+    pooled_vec = torch.zeros(slen, dtype=torch.float64, device=dev)
+
+    def step():
+        for gi, grp in enumerate(groups):
+            pl = plan_for(len(grp))
+            pl.bind(ys[gi], stream)
+            pl.decode_estep(ys[gi], xs[gi], lls[gi], sts[gi], stream)
+            if not args.pooled:
+                pl.mstep(sts[gi], outs[gi], stream)
+            pl.unbind()
+        if args.pooled:
+            pooled_vec.zero_()
+            for gi in range(len(groups)):
+                pooled_vec.add_(sts[gi].sum(0))
+            if dist is not None:
+                if args.backend == "nccl":
+                    dist.all_reduce(pooled_vec)
+                else:
+                    h = pooled_vec.cpu()
+                    dist.all_reduce(h)
+                    pooled_vec.copy_(h)
+            for gi, grp in enumerate(groups):
+                sts[gi][:] = pooled_vec[None, :]
+                plan_for(len(grp)).mstep(sts[gi], outs[gi], stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step()
+    fence()
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    # certificates and near-ties of every group, after the timed region
+    bad = [0, 0, 0, 0]
+    ties_done = 0
+    for gi, grp in enumerate(groups):
+        pl = plan_for(len(grp))
+        pl.viterbi(ys[gi], xs[gi], lls[gi], stream)
+        d1 = pl.diagnostics(stream)
+        ties_done += pl.tie_stats(stream)["decided"]
+        pl.estep(ys[gi], sts[gi], stream)
+        d2 = pl.diagnostics(stream)
+        bad = [bad[0] + d1[0], bad[1] + d2[3], bad[2] + d2[5], bad[3] + d1[7]]
+    if dist is not None:
+        bt = torch.tensor(bad, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(bt)
+        bad = [int(v) for v in bt.tolist()]
+    if rank == 0:
+        roof, info = None, None
+        if groups:
+            pl = plan_for(len(groups[0]))
+            info = pl.info()
+            info["ring_len"] = K - 1
+            gi = 0
+            roof = shape_roofline(pl, info, N, K, T, len(groups[0]), dt / args.steps / max(1, len(groups)), stream,
+                                  lambda: (pl.bind(ys[gi], stream), pl.viterbi(ys[gi], xs[gi], lls[gi], stream),
+                                           pl.estep(ys[gi], sts[gi], stream), pl.mstep(sts[gi], outs[gi], stream),
+                                           pl.unbind()))
+        ms = dt / args.steps * 1e3
+        res = {
+            "metric": "Msamples/sec (Viterbi + forward-backward), K=%d L=%d HMM" % (N, K),
+            "value": total * T / (dt / args.steps) / 1e6, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config %d: %d channels x %d samples, K=%d L=%d HMM (reference N=%d, K=%d: %d "
+                                   "states), channels dealt round-robin over the ranks, %d per batched plan: one Viterbi "
+                                   "decode + one Baum-Welch E-step + M-step finish per channel, %s"
+                                   % (cfg, total, T, N, K, N, K, S, batch,
+                                      "statistics of all channels summed by ONE all-reduce per step (pooled templates: "
+                                      "extension)" if args.pooled else "per-channel models (no collective)"),
+                       "channels": total, "channels_per_rank": len(mine), "samples_per_channel": T, "states": S,
+                       "engine": "wave", "block": info["block"] if info else None, "seed": 1234,
+                       "pooled_allreduce": bool(args.pooled)},
+            "roofline": roof,
+            "detail": {"boundary_check_fails": bad[:3], "near_ties_unresolved": bad[3], "near_ties_resolved_rank0": ties_done,
+                       "workspace_GB": info["workspace_bytes"] / 1e9 if info else None},
+            "valid": bool(bad[0] == 0 and bad[1] == 0 and bad[2] == 0 and bad[3] == 0),
+        }
+        if world == 1 and not args.no_cpu_baseline and not args.quick:
+            res["cpu_baseline"] = cpu_baseline(H, N, K, temps, pp, sigma, Tv=50_000 if cfg == 4 else 20_000,
+                                               Tem=12_000 if cfg == 4 else 4_000, reps=1)
+        print(json.dumps(res))
+        if not res["valid"]:
+            print("bench: certificates failed %s: the line above is INVALID" % (bad,), file=sys.stderr)
+    for pl in plans.values():
+        pl.close()
+
+
+def cpu_baseline(H, N, K, temps, pp, sigma, Tv=100_000, Tem=40_000, reps=4):
     """The oracle (literal restatement of the reference loops) timed on a bounded sample of the same
     workload: Viterbi on 100 000-sample chunks (the reference's own chunk size, src/hmmsort.jl:90)
     and EM steps on 40 000-sample chunks (the reference materialises alpha/beta/gamma; both loops
@@ -106,7 +295,6 @@ def cpu_baseline(H, N, K, temps, pp, sigma):
     from oracle import oracle as O
     O.build()
     sm = O.state_matrix(N, K, np.log(pp), False)
-    Tv, Tem = 100_000, 40_000
 
     def work(seed, reps):
         y = H.create_signal(Tv, 0.3, pp, temps, seed=seed)
@@ -115,7 +303,8 @@ def cpu_baseline(H, N, K, temps, pp, sigma):
             O.viterbi(y, sm, temps, sigma)
         t1 = time.perf_counter()
         for r in range(reps):
-            O.train_step(y[r * 15000:r * 15000 + Tem], sm, np.asfortranarray(temps.copy()), sigma)
+            lo = min(r * 15000, Tv - Tem)
+            O.train_step(y[lo:lo + Tem], sm, np.asfortranarray(temps.copy()), sigma)
         t2 = time.perf_counter()
         return (t1 - t0) / (reps * Tv), (t2 - t1) / (reps * Tem)
 
@@ -125,8 +314,7 @@ def cpu_baseline(H, N, K, temps, pp, sigma):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
-    reps = 4                                       # ~4 s of work per thread (ctypes drops the GIL)
+    cores = max(1, min(cores, 64))                 # reps: ~4 s of work per thread at the headline shape (ctypes drops the GIL)
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(lambda i: work(200 + i, reps), range(cores)))
@@ -139,10 +327,10 @@ def cpu_baseline(H, N, K, temps, pp, sigma):
         "value": single * speedup, "unit": "Msamples/s", "cores": cores, "kind": "port",
         "single_thread_value": single,
         "sample": "oracle (C restatement, gcc -O2 -ffp-contract=off), one thread per chunk on %d host "
-                  "cores: %d x (%d Viterbi decodes of 100k samples + %d EM steps on 40k samples) in "
+                  "cores: %d x (%d Viterbi decodes of %d samples + %d EM steps on %d samples) in "
                   "%.1f s = %.1fx the single thread (Viterbi %.2f, EM step %.4f Msamples/s single "
                   "thread); Julia is not installed, so the reference itself cannot be timed"
-                  % (cores, cores, reps, reps, wall, speedup, 1e-6 / t_vit, 1e-6 / t_em),
+                  % (cores, cores, reps, Tv, reps, Tem, wall, speedup, 1e-6 / t_vit, 1e-6 / t_em),
     }
 
 
@@ -166,6 +354,13 @@ def main():
     ap.add_argument("--states", type=int, default=60, help="states per template (reference K)")
     ap.add_argument("--quick", action="store_true",
                     help="timed region and per-kernel profile only (no CPU baseline, EM loop, multi-channel, overlap extras): for rocprofv3 runs")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
+                    help="BASELINE config: 2 (default; = 3's model) one 10 M-sample channel per GPU, K=4 L=60; "
+                         "4: 64 channels x 10 M samples, K=8 L=128, dealt round-robin over the ranks, 8 channels per "
+                         "batched plan, per-channel training (--pooled: ONE all-reduce of the channel-summed "
+                         "statistics per step, an extension); 5: 8 channels x 100 M samples, K=16 L=256, one per rank")
+    ap.add_argument("--total-channels", type=int, default=0, help="configs 4/5: channels of the whole job (default 64 / 8)")
+    ap.add_argument("--batch", type=int, default=0, help="configs 4/5: channels per batched plan (default 8 / 1)")
     ap.add_argument("--engine", type=int, default=0, help="0 auto (wave), 2 lane-per-chain ring engine, 4 wave")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--halo", type=int, default=0)
@@ -189,6 +384,15 @@ def main():
     assert world == args.gpus, "launch one process per GPU (WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # a stream of our own: the library replays a call's launch sequence as one captured hipGraph, and capture
+    # is not allowed on the legacy null stream (torch's default stream on ROCm)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+
+    if args.config in (4, 5):
+        run_config45(args, torch, H, dist, world, rank, dev)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     # ---- workload: BASELINE config 2/3 model ----
     N, K, T = args.neurons, args.states, args.samples
@@ -207,13 +411,12 @@ def main():
     H.set_option("halo", args.halo)
     T_total = T
     if args.time_sharded and world > 1:
-        s_lo, s_hi, o_lo, o_hi, first, last = H.dist.time_shard(T, rank, world, halo=2048)
-        y = np.ascontiguousarray(y[s_lo:s_hi])
+        # slice + halos; a certified chain boundary inside each halo (dist.time_shard_plan)
+        plan, y, _ = H.dist.time_shard_plan(y, rank, world, sm, temps, sigma, halo=2048)
         T = len(y)
-    plan = H.Plan(T, sm, temps, sigma)
-    if args.time_sharded and world > 1:
-        plan.set_shard(o_lo, o_hi, first, last)
         args.pooled = True   # the shard statistics must be summed before the M-step
+    else:
+        plan = H.Plan(T, sm, temps, sigma)
     info = plan.info()
     info["ring_len"] = K - 1
     assert info["engine"] in (H.ENGINE_RING, H.ENGINE_WAVE)
@@ -292,7 +495,7 @@ def main():
     per_step_ms = {k: v[0] / nprof for k, v in prof.items()}   # ms per step (a kernel may launch more than once)
     dom = max(ksum, key=ksum.get)
     step_ms_kernels = sum(per_step_ms.values())
-    counters, counters_src = measured_traffic(T, info["block"]) if info["engine"] == H.ENGINE_WAVE else (None, None)
+    counters, counters_src = measured_traffic(T, info["block"], N, K) if info["engine"] == H.ENGINE_WAVE else (None, None)
     model = {k: engine_bytes(k, N, T, info) for k in ksum}
     dom_counter = counters.get(dom) if counters else None
     dom_bytes = dom_counter if dom_counter is not None else model.get(dom)
@@ -394,11 +597,16 @@ def main():
         per = (time.perf_counter() - t) / steps
         dg = pl.diagnostics(stream)
         io = pl.info()
+        io["ring_len"] = Kc - 1
+        roof = shape_roofline(pl, io, Nc, Kc, Tc, nchan, per, stream,
+                              lambda: (pl.bind(yy, stream), pl.viterbi(yy, xx, ll_, stream), pl.estep(yy, ss, stream),
+                                       pl.mstep(ss, oo, stream), pl.unbind())) if (Nc, Kc) != (N, K) else None
+        ties = pl.tie_stats(stream)
         pl.close()
         return {"channels_per_gpu": nchan, "model": "N=%d K=%d" % (Nc, Kc), "samples_per_channel": Tc,
                 "Msamples_s": nchan * Tc / per / 1e6, "ms_per_step": per * 1e3, "block": io["block"],
-                "chains": io["nchains"], "boundary_check_fails": [dg[0], dg[3], dg[5]], "near_ties_on_path": dg[7],
-                "workspace_GB": io["workspace_bytes"] / 1e9}
+                "chains": io["nchains"], "boundary_check_fails": [dg[0], dg[3], dg[5]], "near_ties_unresolved": dg[7],
+                "near_ties_resolved": ties["decided"], "workspace_GB": io["workspace_bytes"] / 1e9, "roofline": roof}
 
     def amps_for(Nc):
         base_ = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)]
@@ -480,7 +688,8 @@ def main():
                        "em_iteration_ms": em_ms, "em_sigma_after_10": em_sigma,
                        "multi_channel": mc, "config4_share": cfg4, "config5_shape": cfg5,
                        "overlap_decode": ov,
-                       "diag": diag[:7], "workspace_GB": info["workspace_bytes"] / 1e9},
+                       "diag": diag[:7], "workspace_GB": info["workspace_bytes"] / 1e9,
+                       "near_ties": plan.tie_stats(stream)},
         }
         if world == 1 and not args.no_cpu_baseline and not args.quick:
             res["cpu_baseline"] = cpu_baseline(H, N, K, temps, pp, sigma)

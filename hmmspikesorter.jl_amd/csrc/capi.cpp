@@ -71,7 +71,14 @@ struct HostSlot {
     DevBuf dy, dx, dll, dstats, dout;
     int64_t T = 0, engine_opt = 0, block = 0, halo = 0;
     int device = 0;
-    ~HostSlot() { if (plan) hmmsort_plan_destroy(plan); }
+    // every slot works on a stream of its own and waits for that stream only: host threads that decode or
+    // train at the same time overlap on the device instead of meeting in hipDeviceSynchronize
+    hipStream_t st = nullptr;
+    ~HostSlot()
+    {
+        if (plan) hmmsort_plan_destroy(plan);
+        if (st) (void)hipStreamDestroy(st);
+    }
     void drop_plan()
     {
         if (plan) hmmsort_plan_destroy(plan);
@@ -132,6 +139,10 @@ std::unique_ptr<HostSlot> new_slot(int64_t T, const Options &opt)
     h->block = opt.block;
     h->halo = opt.halo;
     if (hipGetDevice(&h->device) != hipSuccess) (void)hipGetLastError();
+    if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        h->st = nullptr;   // the null stream still works, it only serialises
+    }
     return h;
 }
 
@@ -478,6 +489,22 @@ int hmmsort_plan_set_shard(hmmsort_plan *p, int64_t own_lo, int64_t own_hi, int 
     HS_CHECK((!first || own_lo == 0) && (!last || own_hi == p->T), HMMSORT_EINVAL,
              "plan_set_shard: a first/last shard must own its first/last sample");
     if (p->wave) {
+        // The slice's own ends are arbitrary starts (emission-only first column, beta = 0 at the end): what
+        // certifies that they have been forgotten where the owned range begins / ends is a certified chain
+        // boundary INSIDE each halo -- kw_fb_check compares, at every chain boundary, a warm-up started from
+        // "silent, rings empty" with the neighbouring chain's own sweep, and the two can only agree when
+        // both have forgotten where they started.  So an interior shard edge must have a chain boundary
+        // between the slice end and the owned range.
+        const WaveGeom &g = p->wave->g;
+        const int64_t B = g.B, last_boundary = (int64_t)(g.nch - 1) * B;
+        HS_CHECK(first || (g.nch > 1 && own_lo >= B), HMMSORT_EINVAL,
+                 "plan_set_shard: no chain boundary inside the leading halo (owned range starts at %lld, chains are "
+                 "%lld samples): widen the halo or set a shorter chain length (option \"block\")",
+                 (long long)own_lo, (long long)B);
+        HS_CHECK(last || (g.nch > 1 && own_hi <= last_boundary), HMMSORT_EINVAL,
+                 "plan_set_shard: no chain boundary inside the trailing halo (owned range ends at %lld, last chain "
+                 "boundary at %lld): widen the halo or set a shorter chain length (option \"block\")",
+                 (long long)own_hi, (long long)last_boundary);
         p->wave->g.own_lo = own_lo; p->wave->g.own_hi = own_hi;
         p->wave->g.first = first != 0; p->wave->g.last = last != 0;
         return HMMSORT_OK;
@@ -636,12 +663,12 @@ static int viterbi_host(const void *y, int sample_type, int64_t T, const int16_t
     if ((rc = h.dx.ensure(T * sizeof(int16_t)))) return rc;
     if ((rc = h.dll.ensure(sizeof(double)))) return rc;
     if (sample_type == HMMSORT_SAMPLES_F64) {
-        HS_HIP(hipMemcpy(h.dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
+        HS_HIP(hipMemcpyAsync(h.dy.p, y, T * sizeof(double), hipMemcpyHostToDevice, h.st));
     } else {
         // raw samples: the decoded path's buffer has the size of an int16 signal and is free until the sweep
         HS_CHECK(sample_type == HMMSORT_SAMPLES_I16, HMMSORT_EINVAL, "viterbi: unsupported sample type");
-        HS_HIP(hipMemcpy(h.dx.p, y, T * sizeof(int16_t), hipMemcpyHostToDevice));
-        if ((rc = dev_widen(h.dx.p, sample_type, T, 1, h.dy.as<double>(), nullptr))) return rc;
+        HS_HIP(hipMemcpyAsync(h.dx.p, y, T * sizeof(int16_t), hipMemcpyHostToDevice, h.st));
+        if ((rc = dev_widen(h.dx.p, sample_type, T, 1, h.dy.as<double>(), h.st))) return rc;
     }
     // an idle plan of the same shape: new numbers in, workspace kept.  A list it cannot take (a ring
     // model that stopped being one) falls through to a fresh plan.
@@ -661,24 +688,28 @@ static int viterbi_host(const void *y, int sample_type, int64_t T, const int16_t
             keep = false;
             continue;
         }
-        rc = hmmsort_plan_viterbi(h.plan, h.dy.as<double>(), h.dx.as<int16_t>(), h.dll.as<double>(), nullptr);
+        rc = hmmsort_plan_viterbi(h.plan, h.dy.as<double>(), h.dx.as<int16_t>(), h.dll.as<double>(), h.st);
         if (rc) return rc;
-        HS_HIP(hipDeviceSynchronize());
+        HS_HIP(hipStreamSynchronize(h.st));
         if (h.plan->engine == HMMSORT_ENGINE_STRICT) break;
         int64_t diag[8];
-        if ((rc = hmmsort_plan_diagnostics(h.plan, nullptr, diag))) return rc;
+        if ((rc = hmmsort_plan_diagnostics(h.plan, h.st, diag))) return rc;
         const bool ties = (h.plan->engine == HMMSORT_ENGINE_BLOCKED || h.plan->engine == HMMSORT_ENGINE_WAVE) &&
                           diag[7] != 0;
         if ((diag[0] == 0 && !ties) || !opt.escalate) break;
         if (ties && diag[0] == 0 && opt.engine == HMMSORT_ENGINE_AUTO) {
-            // The op-for-op sweep keeps S x T back-pointers (viterbi.jl:53; 0.8 TB at 4081 states x 10^8 samples:
-            // the reference itself decodes such recordings in chunks, fit.jl:11-42).  When that table cannot be
-            // had, the time-parallel path stands: it differs from the reference's at most at the flagged
-            // decisions, whose margins are inside the reference's own rounding noise.  last_escalations < 0
-            // = minus the number of such decisions.
+            // Decisions the exact resolver could not settle (none on any signal seen): the op-for-op sweep decides.
+            // It keeps back-pointers for the states with more than one incoming transition only (N + 1 of a
+            // ring model: 3.4 GB at 4081 states x 10^8 samples instead of the reference's S x T table, 0.8 TB).
+            // Should even that not fit, the time-parallel path stands: it differs from the reference's at most at
+            // the open decisions, whose margins are inside the reference's own rounding noise.
+            // last_escalations < 0 = minus the number of such decisions.
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-            const double need = (double)S * (double)T * 2.0 + 16.0 * (double)T;
+            int64_t nmulti = 0;
+            for (int64_t j = 0; j < S; j++)
+                nmulti += (h.plan->model.in_ptr[j + 1] - h.plan->model.in_ptr[j]) > 1;
+            const double need = (double)std::max<int64_t>(nmulti, 1) * (double)T * 2.0 + 16.0 * (double)T;
             const double limit = opt.strict_limit_mb > 0 ? (double)opt.strict_limit_mb * 1048576.0 : 0.9 * (double)free_b;
             if (need > limit) {
                 last_escalations() = -diag[7];
@@ -700,8 +731,9 @@ static int viterbi_host(const void *y, int sample_type, int64_t T, const int16_t
         h.drop_plan();
         keep = false;
     }
-    HS_HIP(hipMemcpy(x_out, h.dx.p, T * sizeof(int16_t), hipMemcpyDeviceToHost));
-    HS_HIP(hipMemcpy(ll_out, h.dll.p, sizeof(double), hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpyAsync(x_out, h.dx.p, T * sizeof(int16_t), hipMemcpyDeviceToHost, h.st));
+    HS_HIP(hipMemcpyAsync(ll_out, h.dll.p, sizeof(double), hipMemcpyDeviceToHost, h.st));
+    HS_HIP(hipStreamSynchronize(h.st));
     if (keep) give_slot(std::move(slot), opt);
     return HMMSORT_OK;
 }
@@ -827,7 +859,7 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
     if (!slot) slot = new_slot(T, opt);
     HostSlot &h = *slot;
     if ((rc = h.dy.ensure(T * sizeof(double)))) return rc;
-    HS_HIP(hipMemcpy(h.dy.p, y, T * sizeof(double), hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpyAsync(h.dy.p, y, T * sizeof(double), hipMemcpyHostToDevice, h.st));
     if (h.plan && hmmsort_plan_set_model(h.plan, tr, R, mu_inout, sigma)) h.drop_plan();
     bool keep = true;
     int64_t halo = -1, engine = opt.engine;
@@ -849,11 +881,11 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
         // (the slot key holds neither R nor the engine)
         if ((rc = h.dstats.ensure(hmmsort_plan_stats_len(h.plan) * sizeof(double)))) return rc;
         if ((rc = h.dout.ensure(hmmsort_plan_mstep_len(h.plan) * sizeof(double)))) return rc;
-        if ((rc = hmmsort_plan_estep(h.plan, h.dy.as<double>(), h.dstats.as<double>(), nullptr))) return rc;
-        if ((rc = hmmsort_plan_mstep(h.plan, h.dstats.as<double>(), h.dout.as<double>(), nullptr))) return rc;
-        HS_HIP(hipDeviceSynchronize());
+        if ((rc = hmmsort_plan_estep(h.plan, h.dy.as<double>(), h.dstats.as<double>(), h.st))) return rc;
+        if ((rc = hmmsort_plan_mstep(h.plan, h.dstats.as<double>(), h.dout.as<double>(), h.st))) return rc;
+        HS_HIP(hipStreamSynchronize(h.st));
         int64_t diag[8];
-        if ((rc = hmmsort_plan_diagnostics(h.plan, nullptr, diag))) return rc;
+        if ((rc = hmmsort_plan_diagnostics(h.plan, h.st, diag))) return rc;
         if ((diag[3] == 0 && diag[5] == 0) || !opt.escalate) {
             rc = unpack_mstep(h.dout.as<double>(), K, N, S, nlp, mu_inout, sigma_out, lp_out, lp_cap,
                               n_lp_out, pp_out);
@@ -882,12 +914,12 @@ int hmmsort_em_step(const double *y, int64_t T, const int16_t *states, int64_t N
     if ((rc = da.alloc(st)) || (rc = db.alloc(st)) ||
         (rc = dout.alloc((K * N + 1 + nlp + S) * sizeof(double))))
         return rc;
-    if ((rc = generic_forward(h.plan->gen, h.dy.as<double>(), da.as<double>(), nullptr))) return rc;
-    if ((rc = generic_backward(h.plan->gen, h.dy.as<double>(), db.as<double>(), nullptr))) return rc;
+    if ((rc = generic_forward(h.plan->gen, h.dy.as<double>(), da.as<double>(), h.st))) return rc;
+    if ((rc = generic_backward(h.plan->gen, h.dy.as<double>(), db.as<double>(), h.st))) return rc;
     if ((rc = generic_update(h.plan->gen, da.as<double>(), db.as<double>(), h.dy.as<double>(),
-                             dout.as<double>(), nullptr)))
+                             dout.as<double>(), h.st)))
         return rc;
-    HS_HIP(hipDeviceSynchronize());
+    HS_HIP(hipStreamSynchronize(h.st));
     return unpack_mstep(dout.as<double>(), K, N, S, nlp, mu_inout, sigma_out, lp_out, lp_cap,
                         n_lp_out, pp_out);
 }

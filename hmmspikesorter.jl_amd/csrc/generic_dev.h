@@ -11,7 +11,14 @@ struct GenericDev {
     double *d_mean = nullptr, *d_in_lp = nullptr, *d_out_lp = nullptr, *d_mu = nullptr;
     int32_t *d_in_ptr = nullptr, *d_in_src = nullptr, *d_out_ptr = nullptr, *d_out_dst = nullptr;
     int16_t *d_states = nullptr;
-    int16_t *d_T2 = nullptr;  // S x T back-pointers (viterbi.jl:53), allocated on first decode
+    // back-pointers T2 (viterbi.jl:53) of the strict sweep, kept only where a choice exists: npsi x T entries for
+    // the states with more than one incoming transition (N + 1 of a ring model's 1 + N L states; 236 of the 3600
+    // of the reference's overlap test model); a single-source state's pointer is its source, a state nothing
+    // leads to keeps the reference's initial 1.  d_psidx[j] >= 0: row of state j in T2; < 0: -(implied pointer).
+    int16_t *d_T2 = nullptr;
+    int32_t *d_psidx = nullptr;
+    int npsi = 0;
+    int64_t t2_rows = 0;      // rows d_T2 was allocated for
     double *d_pv = nullptr;   // T path values
     double *d_last = nullptr; // S last trellis column
     double *d_upd = nullptr;  // update() scratch

@@ -44,6 +44,7 @@ __global__ void gen_viterbi_sweep(const double *__restrict__ y, int64_t T, int S
                                   const int32_t *__restrict__ in_ptr,
                                   const int32_t *__restrict__ in_src,
                                   const double *__restrict__ in_lp, double c0, double den,
+                                  const int32_t *__restrict__ psidx, int npsi,
                                   int16_t *__restrict__ T2, double *__restrict__ last,
                                   double *gbuf)
 {
@@ -55,16 +56,14 @@ __global__ void gen_viterbi_sweep(const double *__restrict__ y, int64_t T, int S
     // viterbi.jl:55-63  first column: emission only, then T1[1,1] = 0
     {
         const double y0 = y[0];
-        for (int j = tid; j < S; j += nt) {
-            cur[j] = (j == 0) ? 0.0 : funcl_dev(y0, mean[j], c0, den);
-            T2[j] = 1;
-        }
+        for (int j = tid; j < S; j += nt) cur[j] = (j == 0) ? 0.0 : funcl_dev(y0, mean[j], c0, den);
+        // (the first column of T2 is never read: viterbi.jl:93-94 walks i = nobs .. 2)
     }
     for (int64_t t = 1; t < T; t++) {
         __syncthreads();
         double *tmp = prev; prev = cur; cur = tmp;
         const double yt = y[t];
-        int16_t *psi = T2 + (int64_t)S * t;
+        int16_t *psi = T2 + (int64_t)npsi * t;
         for (int j = tid; j < S; j += nt) {
             double best = -INFINITY;  // viterbi.jl:52 fill(-Inf)
             int arg = 1;              // viterbi.jl:53 ones(Int16)
@@ -77,7 +76,8 @@ __global__ void gen_viterbi_sweep(const double *__restrict__ y, int64_t T, int S
                 }
             }
             cur[j] = best + funcl_dev(yt, mean[j], c0, den);  // :85-87
-            psi[j] = (int16_t)arg;
+            const int pi = psidx[j];
+            if (pi >= 0) psi[pi] = (int16_t)arg;   // single-source states: the pointer is implied
         }
     }
     __syncthreads();
@@ -87,11 +87,18 @@ __global__ void gen_viterbi_sweep(const double *__restrict__ y, int64_t T, int S
 // argmax (first maximum, viterbi.jl:90) + backtrace (:93-94).  One block; T2 columns are staged
 // through LDS in coalesced bulk so the serial walk never waits on HBM.
 __global__ void gen_viterbi_backtrace(const int16_t *__restrict__ T2, const double *__restrict__ last,
+                                      const int32_t *__restrict__ psidx, int npsi, int idx_in_lds,
                                       int64_t T, int S, int W, int16_t *__restrict__ x)
 {
-    extern __shared__ int16_t shp[];  // W columns of S entries
+    extern __shared__ int16_t shp[];  // W columns of npsi entries | (idx_in_lds) psidx[S]
     __shared__ int cur_state;
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int32_t *pidx = psidx;
+    if (idx_in_lds) {
+        int32_t *li = reinterpret_cast<int32_t *>(shp + (((size_t)W * npsi + 1) & ~(size_t)1));
+        for (int j = tid; j < S; j += nt) li[j] = psidx[j];
+        pidx = li;
+    }
     if (tid == 0) {
         int best = 0;
         for (int j = 1; j < S; j++)
@@ -105,14 +112,15 @@ __global__ void gen_viterbi_backtrace(const int16_t *__restrict__ T2, const doub
         if (lo < 1) lo = 1;
         const int64_t ncol = hi - lo + 1;
         __syncthreads();
-        const int64_t nel = ncol * S;
-        const int16_t *srcp = T2 + (int64_t)S * lo;
+        const int64_t nel = ncol * npsi;
+        const int16_t *srcp = T2 + (int64_t)npsi * lo;
         for (int64_t e = tid; e < nel; e += nt) shp[e] = srcp[e];
         __syncthreads();
         if (tid == 0) {
             int xs = cur_state;
             for (int64_t i = hi; i >= lo; i--) {
-                xs = shp[(i - lo) * S + (xs - 1)];
+                const int pi = pidx[xs - 1];
+                xs = pi >= 0 ? (int)shp[(i - lo) * npsi + pi] : -pi;
                 x[i - 1] = (int16_t)xs;
             }
             cur_state = xs;
@@ -397,6 +405,16 @@ int generic_set_model(GenericDev *g, const HostModel &m)
     if ((rc = upload(&g->d_mu, m.mu, &g->bytes))) return rc;
     if ((rc = upload(&g->d_states, m.states, &g->bytes))) return rc;
     g->nsrc1 = m.out_ptr[1] - m.out_ptr[0];
+    {
+        std::vector<int32_t> idx(m.S);
+        int np = 0;
+        for (int64_t j = 0; j < m.S; j++) {
+            const int deg = m.in_ptr[j + 1] - m.in_ptr[j];
+            idx[j] = deg > 1 ? np++ : -(deg == 1 ? m.in_src[m.in_ptr[j]] + 1 : 1);
+        }
+        g->npsi = np > 0 ? np : 1;
+        if ((rc = upload(&g->d_psidx, idx, &g->bytes))) return rc;
+    }
     if (g->blocked) return blocked_set_model(g, m);
     return HMMSORT_OK;
 }
@@ -437,7 +455,7 @@ void generic_destroy(GenericDev *g)
     if (!g) return;
     void *ptrs[] = {g->d_mean, g->d_in_lp, g->d_out_lp, g->d_mu, g->d_in_ptr, g->d_in_src,
                     g->d_out_ptr, g->d_out_dst, g->d_states, g->d_T2, g->d_pv, g->d_last,
-                    g->d_upd, g->d_gbuf};
+                    g->d_upd, g->d_gbuf, g->d_psidx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     blocked_destroy(g);
@@ -478,15 +496,18 @@ int generic_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
 {
     const int64_t T = g->T, S = g->S;
     if (g->blocked) return blocked_viterbi(g, d_y, d_x, d_ll, st);
-    if (!g->d_T2) {
-        const double need = (double)S * (double)T * 2.0 + (double)T * 8.0;
+    if (!g->d_T2 || g->t2_rows < g->npsi) {
+        if (g->d_T2) { (void)hipFree(g->d_T2); g->d_T2 = nullptr; g->bytes -= g->t2_rows * T * 2; }
+        const double need = (double)g->npsi * (double)T * 2.0 + (double)T * 8.0;
         HS_CHECK(need < 200e9, HMMSORT_ENOMEM,
                  "strict Viterbi needs %.1f GB of back-pointers; decode in chunks", need / 1e9);
-        if (hipMalloc((void **)&g->d_T2, (size_t)S * T * sizeof(int16_t)) != hipSuccess ||
-            hipMalloc((void **)&g->d_pv, (size_t)T * sizeof(double)) != hipSuccess) {
+        if (hipMalloc((void **)&g->d_T2, (size_t)g->npsi * T * sizeof(int16_t)) != hipSuccess ||
+            (!g->d_pv && hipMalloc((void **)&g->d_pv, (size_t)T * sizeof(double)) != hipSuccess)) {
+            (void)hipGetLastError();
             set_error("strict Viterbi: hipMalloc of %.1f GB failed", need / 1e9);
             return HMMSORT_ENOMEM;
         }
+        g->t2_rows = g->npsi;
         g->bytes += (int64_t)need;
     }
     const double c0 = -kLog2Pi - g->lsig;
@@ -495,15 +516,16 @@ int generic_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     int rc = set_lds_limit((const void *)gen_viterbi_sweep, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(gen_viterbi_sweep, dim3(1), dim3(g->threads), lds, st, d_y, T, (int)S,
-                       g->d_mean, g->d_in_ptr, g->d_in_src, g->d_in_lp, c0, den, g->d_T2,
-                       g->d_last, g->use_global ? g->d_gbuf : nullptr);
+                       g->d_mean, g->d_in_ptr, g->d_in_src, g->d_in_lp, c0, den, g->d_psidx, g->npsi,
+                       g->d_T2, g->d_last, g->use_global ? g->d_gbuf : nullptr);
     HS_HIP(hipGetLastError());
-    int W = (int)std::max<int64_t>(1, (48 * 1024) / (S * 2));
-    size_t lds2 = (size_t)W * S * sizeof(int16_t);
+    int W = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (48 * 1024) / ((int64_t)g->npsi * 2)));
+    const int idx_in_lds = S * 4 <= 96 * 1024 ? 1 : 0;   // the per-state row index beside the staged columns
+    size_t lds2 = (((size_t)W * g->npsi + 1) & ~(size_t)1) * sizeof(int16_t) + (idx_in_lds ? (size_t)S * 4 : 0);
     rc = set_lds_limit((const void *)gen_viterbi_backtrace, lds2);
     if (rc) return rc;
-    hipLaunchKernelGGL(gen_viterbi_backtrace, dim3(1), dim3(256), lds2, st, g->d_T2, g->d_last, T,
-                       (int)S, W, d_x);
+    hipLaunchKernelGGL(gen_viterbi_backtrace, dim3(1), dim3(256), lds2, st, g->d_T2, g->d_last, g->d_psidx,
+                       g->npsi, idx_in_lds, T, (int)S, W, d_x);
     HS_HIP(hipGetLastError());
     hipLaunchKernelGGL(gen_viterbi_ll, dim3(1), dim3(64), 0, st, d_y, d_x, T, g->d_mean,
                        g->d_in_ptr, g->d_in_src, g->d_in_lp, c0, den, g->d_pv, d_ll);

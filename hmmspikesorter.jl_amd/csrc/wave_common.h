@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cmath>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -111,13 +112,19 @@ struct WaveDev {
     double *dbg = nullptr;            // 64 doubles: debug record of the first failing certificate
     // exact near-tie resolver (wave_ties.hip)
     int64_t *tie_cnt = nullptr;       // C x 8 counters (kTie* below)
-    int64_t *tie_list = nullptr;      // C x kTieCap flagged decisions on the decoded path: t * 32 + entry
+    int64_t *tie_list = nullptr;      // C x kTieCap flagged decisions on the decoded path: t * 32 + entry, time order
+    int64_t *tie_off = nullptr;       // C x (ntile + 1) list offsets of the tiles of 4096 samples
+    int64_t tie_ntile = 0;
     int16_t *tie_walk = nullptr;      // C x kTieLanes x kTieWalk candidate paths (newest sample first)
     double *tie_guess = nullptr;      // C x nblk approximate trellis value at every block start
     double *tie_c = nullptr;          // C x nblk x 2 exact block increments for an even / odd start value
     int32_t *tie_ok = nullptr;        // C x nblk block increments usable (one binade, path unchanged)
     double *tie_v = nullptr;          // C x (nblk + 1) exact trellis values of the decoded path at block starts
     int64_t tie_nblk = 0;
+    // captured launch sequences (wave_graphed below)
+    struct GraphEntry { uint64_t key[12]; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    bool graphs_on = true;
     int64_t bytes = 0;
     int nparts = 0, gparts = 0;
 };
@@ -281,7 +288,7 @@ __device__ __forceinline__ double wave_sum(double v)
 
 // ---- exact near-tie resolver (wave_ties.hip) ------------------------------------------------------
 constexpr int kTieBlk = 512;                 // samples per block of the exact prefix
-constexpr int kTieCap = 4096;                // flagged decisions on the decoded path kept per channel
+constexpr int kTieCap = 65536;               // flagged decisions on the decoded path kept per channel
 constexpr int kTieWalk = 8192;               // longest candidate walk before it must have met the decoded path
 constexpr int kTieLanes = 64;                // candidates of one decision (junctions: silent + N ring exits; final arg-max: end states)
 // tie_cnt[ch * 8 + i]
@@ -314,6 +321,60 @@ __device__ __forceinline__ double wave_thr(const WaveGeom &g, const WaveConst &K
     const double sq = fmax((s2 - 2.0 * K.mean0 * s1) + T * K.mean0 * K.mean0, 0.0);
     const double mmax = fabs(K.A) * T + sq / K.den + fabs(K.c00) * T + 1.0;
     return (ldexp(16.0 * (double)(g.L + 2), ilogb(mmax) - 52) + 4.0e-9) * g.thr_scale;
+}
+
+// A call's launch sequence (two dozen kernels, memsets and cross-stream events on three streams) as ONE
+// hipGraph launch: the sequence is captured the first time a call is made with a given set of buffer
+// pointers and launch-relevant plan state, and replayed afterwards (model constants live in device tables,
+// so hmmsort_plan_set_model does not invalidate it).  Not on the legacy null stream (capture is not allowed
+// there), not while per-kernel profiling brackets the launches; any capture failure switches the plan back
+// to plain launches for good.
+template <typename F>
+int wave_graphed(WaveDev *r, int kind, const void *p0, const void *p1, const void *p2, const void *p3,
+                 hipStream_t st, F enqueue)
+{
+    if (!r->graphs_on || r->prof_on || st == nullptr) return enqueue(st);
+    uint64_t key[12] = {(uint64_t)kind, (uint64_t)(uintptr_t)p0, (uint64_t)(uintptr_t)p1, (uint64_t)(uintptr_t)p2,
+                        (uint64_t)(uintptr_t)p3, (uint64_t)(uintptr_t)st, (uint64_t)(r->bound_y == p0),
+                        (uint64_t)r->uniform_cx, (uint64_t)r->g.own_lo, (uint64_t)r->g.own_hi,
+                        (uint64_t)(r->g.first * 2 + r->g.last), (uint64_t)(uint32_t)r->g.tie_debug};
+    {
+        uint64_t tb;
+        static_assert(sizeof(tb) == sizeof(r->g.thr_scale), "");
+        memcpy(&tb, &r->g.thr_scale, sizeof(tb));
+        key[11] ^= tb << 8;
+    }
+    for (auto &e : r->graphs)
+        if (!memcmp(e.key, key, sizeof(key))) {
+            HS_HIP(hipGraphLaunch(e.exec, st));
+            return HMMSORT_OK;
+        }
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        r->graphs_on = false;
+        return enqueue(st);
+    }
+    const int rc = enqueue(st);
+    hipGraph_t graph = nullptr;
+    const hipError_t e1 = hipStreamEndCapture(st, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (rc || e1 != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        r->graphs_on = false;
+        return rc ? rc : enqueue(st);
+    }
+    (void)hipGraphDestroy(graph);
+    if (r->graphs.size() >= 16) {   // callers that cycle through many buffers: forget the oldest
+        (void)hipGraphExecDestroy(r->graphs.front().exec);
+        r->graphs.erase(r->graphs.begin());
+    }
+    WaveDev::GraphEntry ge;
+    memcpy(ge.key, key, sizeof(key));
+    ge.exec = exec;
+    r->graphs.push_back(ge);
+    HS_HIP(hipGraphLaunch(exec, st));
+    return HMMSORT_OK;
 }
 
 // wave_engine.hip

@@ -192,6 +192,9 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
     int rc = make_geometry(r->g, T, C, m.ring.N, m.ring.L, block_req, halo_req);
     if (rc) { delete r; return rc; }
     r->S = m.S; r->K = m.K;
+    // captured launch sequences are opt-in: measured SLOWER than plain launches on ROCm 7.2 (headline step 1.24
+    // against 1.11 ms: the replay does not overlap the decode branch with the E-step chain like three streams do)
+    r->graphs_on = getenv("HMMSORT_GRAPHS") && atoi(getenv("HMMSORT_GRAPHS")) != 0;
     r->ring.resize(C); r->mean.resize(C); r->sigma.resize(C); r->ucx.assign(C, 1);
     const WaveGeom &g = r->g;
     const int64_t N = g.N, L = g.L, CT = (int64_t)C * T, nchT = (int64_t)C * g.nch;
@@ -238,6 +241,8 @@ int wave_create(WaveDev **out, const std::vector<HostModel> &models, int64_t T, 
     r->tie_nblk = (T + kTieBlk - 1) / kTieBlk;
     A(&r->tie_cnt, (int64_t)C * 8);
     A(&r->tie_list, (int64_t)C * kTieCap);
+    r->tie_ntile = (T + 4095) / 4096;
+    A(&r->tie_off, (int64_t)C * (r->tie_ntile + 1));
     A(&r->tie_walk, (int64_t)C * kTieLanes * kTieWalk);
     A(&r->tie_guess, (int64_t)C * r->tie_nblk);
     A(&r->tie_c, (int64_t)C * r->tie_nblk * 2);
@@ -300,7 +305,7 @@ void wave_destroy(WaveDev *r)
     void *ptrs[] = {r->d_cst, r->d_mean, r->d_meanT, r->d_cint, r->d_msq, r->d_ctab, r->d_states, r->Rf, r->W2, r->virt, r->ysum,
                     r->psi, r->vpre, r->vend, r->vfail, r->bstate, r->redo, r->final_state, r->part, r->FA0,
                     r->FV, r->FREF, r->fpre, r->bpre, r->bown, r->rho, r->Zc, r->partS, r->partG, r->yhead,
-                    r->extra, r->pp, r->diag, r->dbg, r->trash, r->tie_cnt, r->tie_list, r->tie_walk, r->tie_guess,
+                    r->extra, r->pp, r->diag, r->dbg, r->trash, r->tie_cnt, r->tie_list, r->tie_off, r->tie_walk, r->tie_guess,
                     r->tie_c, r->tie_ok, r->tie_v};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -312,6 +317,7 @@ void wave_destroy(WaveDev *r)
     if (r->side) (void)hipStreamDestroy(r->side);
     if (r->side2) (void)hipStreamDestroy(r->side2);
     for (auto &e : r->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &ge : r->graphs) (void)hipGraphExecDestroy(ge.exec);
     delete r;
 }
 

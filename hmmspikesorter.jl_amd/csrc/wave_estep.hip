@@ -301,15 +301,17 @@ struct BIn {
     double fref, la0; // fref(t+1), la0(t)
 };
 
-// FUSE (3-4 rings of at most 64 states): the spike-triggered sums G1[a][lag] = sum_t' rho_a(t') y(t' + lag) are
-// accumulated by the sweep itself on the matrix cores, so rho is not read back by a statistics kernel.  The sweep
-// runs backward in time; with sigma = step index (rising while t' falls) the product pairs rho(sigma) with
-// y(sigma - lag), i.e. with samples the sweep has already seen.  Per v_mfma_f64_16x16x4_f64:
-//   A[i][kk] = Y(tau + kk - 48 - i),  B[kk][a + 4 s'] = rho_a(tau + kk - 16 s')   =>  lag = 16 (3 - s') + i,
-// four delayed copies of the four rings fill the 16 columns, one accumulator tile holds all 64 lags.  rho and y
-// of the last ~128 steps live in two LDS rings of the wave; a super-step of W steps feeds W/4 MFMAs (the
-// remainder waits for the next one), and after the last step the copies are drained with zeros.
-template <int N, bool UC, bool FUSE = false>
+// FT > 0 (fused statistics; 3-4 rings of at most 64 states: FT = 1; 5-8 rings of at most 64 / 128 states: FT = 2 / 4):
+// the spike-triggered sums G1[a][lag] = sum_t' rho_a(t') y(t' + lag) are accumulated by the sweep itself on the
+// matrix cores, so rho is not read back by a statistics kernel.  The sweep runs backward in time; with
+// sigma = step index (rising while t' falls) the product pairs rho(sigma) with y(sigma - lag), i.e. with samples
+// the sweep has already seen.  Per v_mfma_f64_16x16x4_f64 and accumulator tile q:
+//   A_q[i][kk] = Y(tau + kk - D_q - i),  B[kk][a + NP s'] = rho_a(tau + kk - 16 s')   =>  lag = D_q - 16 s' + i,
+// NS = 16 / NP delayed copies of the NP (4 or 8) ring columns fill the 16 columns, D_q = 16 NS q + 16 (NS - 1):
+// tile q holds the 16 NS lags from 16 NS q of every ring, FT tiles hold them all (B is read once per FT MFMAs).
+// rho and y of the last few hundred steps live in two LDS rings of the wave; a super-step of W steps feeds
+// FT W/4 MFMAs (the remainder waits for the next one), and after the last step the copies are drained with zeros.
+template <int N, bool UC, int FT = 0>
 __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const WaveConst *__restrict__ cst,
                                                             const double *__restrict__ y,
                                                             const double *__restrict__ Rf,
@@ -323,7 +325,14 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
                                                             double *__restrict__ bown, double *__restrict__ yhead,
                                                             double *__restrict__ trash, double *__restrict__ partG)
 {
-    static_assert(!FUSE || (N >= 3 && N <= 4), "the fused statistics are written for four delayed copies of 3-4 rings");
+    constexpr bool FUSE = FT > 0;
+    static_assert(!FUSE || (N >= 3 && N <= 8), "the fused statistics are written for delayed copies of 3-8 rings");
+    static_assert(!FUSE || N > 4 || FT == 1, "3-4 rings: one tile of 64 lags");
+    constexpr int NPc = N <= 4 ? 4 : 8, NSc = 16 / NPc, LPT = 16 * NSc;   // ring columns per copy, copies, lags per tile
+    constexpr int RPAD = NPc == 4 ? 1 : 2;                   // padding rows per 16 rows of the rho ring (bank spread of the copies)
+    constexpr int RGROWS = 128 + 8 * RPAD;
+    constexpr int YM = (FT * LPT + 16 * (NSc - 1) + 160) <= 256 ? 256 : 512;   // y ring: largest lag + step width + slack
+    constexpr int NACC = FT <= 1 ? 2 : FT;                   // FT = 1: two tiles alternate (independent MFMA chains)
     constexpr int D = N <= 4 ? 3 : (N <= 8 ? 2 : 1);   // input pipeline depth in super-steps (4 with the fused statistics: spills, 0.70 ms)
     constexpr int KSC = 4, KCP0 = 4 + N, KPEND = 4 + 2 * N, KCPX = 4 + 3 * N, KSIZE = 4 + 3 * N + N * N;
     extern __shared__ double lds[];
@@ -348,32 +357,49 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
 
     for (int i = lane; i < N * (RB + 1); i += 64) DLv[i] = 1.0;
     for (int i = lane; i < RB + 1; i += 64) DLs[i] = 0.0;
-    // fused statistics: y ring (256 steps) | rho ring (128 steps x 4 rings, one padding row per 16)
-    double *YY = DLs + (RB + 1), *RG = YY + 256;
-    const int lk = lane >> 4, lj = lane & 15, gla = lj & 3, glsft = lj >> 2;
-    wg_d4 cacc = wg_d4{0.0, 0.0, 0.0, 0.0}, cacc2 = wg_d4{0.0, 0.0, 0.0, 0.0};   // two tiles: independent MFMA chains
+    // fused statistics: y ring (YM steps) | rho ring (128 steps x NPc ring columns, RPAD padding rows per 16)
+    double *YY = DLs + (RB + 1), *RG = YY + YM;
+    const int lk = lane >> 4, lj = lane & 15, gla = lj % NPc, glsft = lj / NPc;
+    wg_d4 cacc[NACC > 0 ? NACC : 1];
+#pragma unroll
+    for (int q = 0; q < NACC; q++) cacc[q] = wg_d4{0.0, 0.0, 0.0, 0.0};
     int gtau = -1;                                       // next tau of the product, -1: no owned step yet
-    // products for tau = gtau, gtau + 4, ... while tau + 4 <= upto, two at a time on two accumulator tiles
-    // (independent MFMA chains).  Reading the operands of a whole super-step first and issuing 16 MFMAs back to
-    // back was slower (0.427 vs 0.400 ms: 64 more live VGPRs).
+    auto rgrow = [&](int r) { return (r + RPAD * (r >> 4)) * NPc; };
+    // products for tau = gtau, gtau + 4, ... while tau + 4 <= upto.  FT = 1: two at a time on two accumulator
+    // tiles (independent MFMA chains); FT > 1: the FT tiles of one tau are independent of each other.  Reading the
+    // operands of a whole super-step first and issuing 16 MFMAs back to back was slower (0.427 vs 0.400 ms: 64
+    // more live VGPRs).
     auto gmfma = [&](int upto) {
-        for (; gtau + 8 <= upto; gtau += 8) {
-            const int r0 = (gtau + lk - 16 * glsft) & 127, r1 = (gtau + 4 + lk - 16 * glsft) & 127;
-            const double b0 = RG[(r0 + (r0 >> 4)) * 4 + gla], b1 = RG[(r1 + (r1 >> 4)) * 4 + gla];
-            const double a0 = YY[(gtau + lk - 48 - lj) & 255], a1 = YY[(gtau + 4 + lk - 48 - lj) & 255];
-            cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, cacc, 0, 0, 0);
-            cacc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, cacc2, 0, 0, 0);
-        }
-        if (gtau + 4 <= upto) {
-            const int r0 = (gtau + lk - 16 * glsft) & 127;
-            const double b0 = RG[(r0 + (r0 >> 4)) * 4 + gla];
-            const double a0 = YY[(gtau + lk - 48 - lj) & 255];
-            cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, cacc, 0, 0, 0);
-            gtau += 4;
+        if constexpr (FT <= 1) {
+            constexpr int D0 = 16 * (NSc - 1);
+            for (; gtau + 8 <= upto; gtau += 8) {
+                const int r0 = (gtau + lk - 16 * glsft) & 127, r1 = (gtau + 4 + lk - 16 * glsft) & 127;
+                const double b0 = RG[rgrow(r0) + gla], b1 = RG[rgrow(r1) + gla];
+                const double a0 = YY[(gtau + lk - D0 - lj) & (YM - 1)], a1 = YY[(gtau + 4 + lk - D0 - lj) & (YM - 1)];
+                cacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, cacc[0], 0, 0, 0);
+                cacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, cacc[1], 0, 0, 0);
+            }
+            if (gtau + 4 <= upto) {
+                const int r0 = (gtau + lk - 16 * glsft) & 127;
+                const double b0 = RG[rgrow(r0) + gla];
+                const double a0 = YY[(gtau + lk - D0 - lj) & (YM - 1)];
+                cacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, cacc[0], 0, 0, 0);
+                gtau += 4;
+            }
+        } else {
+            for (; gtau + 4 <= upto; gtau += 4) {
+                const int r0 = (gtau + lk - 16 * glsft) & 127;
+                const double b0 = RG[rgrow(r0) + gla];
+                double av[FT];
+#pragma unroll
+                for (int q = 0; q < FT; q++) av[q] = YY[(gtau + lk - (LPT * q + 16 * (NSc - 1)) - lj) & (YM - 1)];
+#pragma unroll
+                for (int q = 0; q < FT; q++) cacc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], b0, cacc[q], 0, 0, 0);
+            }
         }
     };
     if (FUSE) {
-        for (int i = lane; i < 256 + 136 * 4; i += 64) YY[i] = 0.0;
+        for (int i = lane; i < YM + RGROWS * NPc; i += 64) YY[i] = 0.0;
     }
     {
         const WaveConst &Kg = cst[ch];
@@ -429,7 +455,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
         const int64_t tb = te - 2 - done;                // time of lane 0
         const int64_t t = tb - lane;                     // step index i = done + 1 + lane, t = te-1-i
         const bool owned = MODE == 1 || MODE == 3 || (MODE == 2 && done >= n_warm);   // wave-uniform
-        if (FUSE) YY[(done + 1 + lane) & 255] = d.y1;    // y of this lane's onset time t+1 (idle lanes: steps still to come)
+        if (FUSE) YY[(done + 1 + lane) & (YM - 1)] = d.y1;    // y of this lane's onset time t+1 (idle lanes: steps still to come)
         int ws = (done + 1) % RB + lane;                 // (done+1) % RB is wave-uniform
         ws = ws >= RB ? ws - RB : ws;
         int rs = ws - L;
@@ -528,16 +554,11 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
                 ra[a] += bulk ? rv : 0.0;
                 s2[a] = __builtin_fma(rv, d.w2, s2[a]);          // sum_k G2(a,k) (baumwelch.jl:302)
                 sx[a] += (own1 && t >= 0) ? wa[a] * gg[0] : 0.0;  // xi'_a(t+1): silent(t) -> (a,1)(t+1), :240
-                if (FUSE) {
-                    const int slot = (done + 1 + lane) & 127;
-                    RG[(slot + (slot >> 4)) * 4 + a] = rv;       // idle lanes: zeros at steps still to come
-                }
+                if (FUSE) RG[rgrow((done + 1 + lane) & 127) + a] = rv;   // idle lanes: zeros at steps still to come
             }
             if (FUSE) {
-                if (N == 3) {
-                    const int slot = (done + 1 + lane) & 127;
-                    RG[(slot + (slot >> 4)) * 4 + 3] = 0.0;
-                }
+#pragma unroll
+                for (int a = N; a < NPc; a++) RG[rgrow((done + 1 + lane) & 127) + a] = 0.0;
                 if (gtau < 0) gtau = (done + 1) & ~3;            // wave-uniform
                 gmfma(done + 1 + nact);
             }
@@ -653,18 +674,18 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
         const int sig_end = n_total + 1;
         if (gtau >= 0) {
 #pragma unroll
-            for (int a = 0; a < 4; a++) {
-                const int slot = (sig_end + lane) & 127;
-                RG[(slot + (slot >> 4)) * 4 + a] = 0.0;
-            }
-            gmfma(sig_end + 52);                               // tau up to sig_end + 48
+            for (int a = 0; a < NPc; a++) RG[rgrow((sig_end + lane) & 127) + a] = 0.0;
+            gmfma(sig_end + 16 * (NSc - 1) + 4);               // tau up to sig_end + 16 (NS - 1): the last delayed copy
         }
         double *pg = partG + (int64_t)cg * N * L;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int lag = 16 * (3 - glsft) + lk + 4 * r;
-            if (gla < N && lag < L) pg[gla * L + lag] = cacc[r] + cacc2[r];
-        }
+        for (int q = 0; q < (FT <= 1 ? 1 : FT); q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int lag = LPT * q + 16 * (NSc - 1 - glsft) + lk + 4 * r;
+                const double v = FT <= 1 ? cacc[0][r] + cacc[1][r] : cacc[q][r];
+                if (gla < N && lag < L) pg[gla * L + lag] = v;
+            }
     }
     // per-chain partial sums -> partS[cg][3N+3] = sx | ra | s2 | s_all s_m s_y2
     double *ps = partS + (int64_t)cg * (3 * N + 3);
@@ -913,25 +934,27 @@ __global__ __launch_bounds__(256) void kw_gsum_mx(WaveGeom g, const double *__re
             }
         }
     }
-    // sum the four waves' tiles: LDS [wave][NT][4 regs][64 lanes]
-    __syncthreads();
+    // sum the four waves' tiles, one accumulator tile at a time: LDS [wave][4 regs][64 lanes] (all NT tiles at once
+    // would take 8 KB x NT of LDS: with 8 tiles that halved the occupancy, 16 would not fit beside the staging)
+    const int NL = N * L;
+    double *out = partG + ((int64_t)ch * nparts + blockIdx.x) * NL;
     double *red = lds;
 #pragma unroll
     for (int q = 0; q < NT; q++) {
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; r++) red[((wv * NT + q) * 4 + r) * 64 + lane] = c1[q][r];
-    }
-    __syncthreads();
-    const int NL = N * L;
-    double *out = partG + ((int64_t)ch * nparts + blockIdx.x) * NL;
-    for (int e = tid; e < NT * 4 * 64; e += 256) {
-        const int ln = e & 63, r = (e >> 6) & 3, q = e >> 8;
-        double v = 0.0;
+        for (int r = 0; r < 4; r++) red[(wv * 4 + r) * 64 + lane] = c1[q][r];
+        __syncthreads();
+        {
+            const int e = tid;                       // 256 threads = 4 regs x 64 lanes
+            const int ln = e & 63, r = e >> 6;
+            double v = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) v += red[((w * NT + q) * 4 + r) * 64 + ln];
-        const int j = ln & 15, a = j % NP, sft = j / NP;
-        const int lag = lag0 + q * LPT + 16 * sft + (ln >> 4) + 4 * r;
-        if (a < N && lag < L) out[a * L + lag] = v;
+            for (int w = 0; w < 4; w++) v += red[(w * 4 + r) * 64 + ln];
+            const int j = ln & 15, a = j % NP, sft = j / NP;
+            const int lag = lag0 + q * LPT + 16 * sft + (ln >> 4) + 4 * r;
+            if (a < N && lag < L) out[a * L + lag] = v;
+        }
     }
 }
 
@@ -1065,14 +1088,24 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
         constexpr int NN = decltype(n)::value;
         const size_t ldsf = ((size_t)(NN > 8 ? 1 : 2) * NN * (g.RB + 1) + 5 + 3 * NN + NN * NN) * sizeof(double);
         const bool generic = getenv("HMMSORT_GSUM_GENERIC") != nullptr;
-        // 3-4 rings of at most 64 states: the backward sweep accumulates G1 itself (matrix cores, LDS rings)
-        constexpr bool kCanFuse = NN == 3 || NN == 4;
-        const bool fuse = kCanFuse && L <= 64 && !generic && getenv("HMMSORT_GSUM_SEPARATE") == nullptr;
-        const size_t ldsb = ((size_t)(NN + 1) * (g.RB + 1) + 4 + 3 * NN + NN * NN + (fuse ? 256 + 136 * 4 : 0)) * sizeof(double);
+        // 3-4 rings of at most 64 states, 5-8 rings of at most 128 (uniform exit -> entry values): the backward
+        // sweep accumulates G1 itself (matrix cores, LDS rings)
+        constexpr bool kFuse4 = NN == 3 || NN == 4, kFuse8 = NN >= 5 && NN <= 8;
+        const bool sep = generic || getenv("HMMSORT_GSUM_SEPARATE") != nullptr;
+        const int ft = sep ? 0 : (kFuse4 && L <= 64) ? 1 : (kFuse8 && r->uniform_cx && L <= 64) ? 2
+                       : (kFuse8 && r->uniform_cx && L <= 128) ? 4 : 0;
+        const bool fuse = ft > 0;
+        const int ym = ft <= 1 ? 256 : ((ft * 32 + 16 + 160) <= 256 ? 256 : 512);
+        const size_t ldsb = ((size_t)(NN + 1) * (g.RB + 1) + 4 + 3 * NN + NN * NN +
+                             (fuse ? ym + (128 + 8 * (NN <= 4 ? 1 : 2)) * (NN <= 4 ? 4 : 8) : 0)) * sizeof(double);
         auto kf = r->uniform_cx ? kw_fwd<NN, true> : kw_fwd<NN, false>;
         auto kb = r->uniform_cx ? kw_bwd<NN, true> : kw_bwd<NN, false>;
-        if constexpr (kCanFuse) {
-            if (fuse) kb = r->uniform_cx ? kw_bwd<NN, true, true> : kw_bwd<NN, false, true>;
+        if constexpr (kFuse4) {
+            if (ft == 1) kb = r->uniform_cx ? kw_bwd<NN, true, 1> : kw_bwd<NN, false, 1>;
+        }
+        if constexpr (kFuse8) {
+            if (ft == 2) kb = kw_bwd<NN, true, 2>;
+            if (ft == 4) kb = kw_bwd<NN, true, 4>;
         }
         int rc2;
         if ((rc2 = wave_lds_attr2(kf, ldsf)) || (rc2 = wave_lds_attr2(kb, ldsb))) return rc2;
@@ -1098,12 +1131,14 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
         if (fuse) {
             rowsG = g.nch;                      // partG[ch][chain][N L], written by kw_bwd
         } else if (!generic) {
-            // up to 4 accumulator tiles per workgroup; longer rings take one pass over rho per group of 4
-            const int ntk = NN > 8 ? 4 : (ntx < 4 ? ntx : 4), ngrp = (ntx + ntk - 1) / ntk;
+            // up to 4 accumulator tiles per workgroup for N <= 8 (longer rings take one pass over rho per group of
+            // 4); more than 8 rings (16 lags per tile): 8 or 16 tiles, so that rings of up to 255 states need ONE
+            // pass over rho instead of four (config 5's shape: 128 B of posteriors per sample and pass)
+            const int ntk = NN > 8 ? (ntx <= 4 ? 4 : (ntx <= 8 ? 8 : 16)) : (ntx < 4 ? ntx : 4), ngrp = (ntx + ntk - 1) / ntk;
             rowsG = (int)((g.T + kGxSubs * 8 * (int64_t)kGxBv - 1) / (kGxSubs * 8 * (int64_t)kGxBv));
             constexpr int RRx = kGxTR + HSx, RRPx = RRx + RRx / 16 + 1;
             const size_t l1 = ((size_t)8 * (RRPx * NPx + 2) + (size_t)8 * (kGxTR + 19 + LPTx * (ntk - 1))) * 8;
-            const size_t l2 = (size_t)4 * ntk * 4 * 64 * 8;
+            const size_t l2 = (size_t)4 * 4 * 64 * 8;
             const size_t lds = l1 > l2 ? l1 : l2;
             auto go = [&](auto kern) -> int {
                 int rc3 = wave_lds_attr2(kern, lds);
@@ -1112,7 +1147,7 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
                 hipLaunchKernelGGL(kern, dim3(rowsG, g.C, ngrp), dim3(256), lds, st, g, d_y, r->rho, rowsG, r->partG);
                 return HMMSORT_OK;
             };
-            if constexpr (NN > 8) rc2 = go(kw_gsum_mx<NN, 4>);
+            if constexpr (NN > 8) rc2 = ntk == 4 ? go(kw_gsum_mx<NN, 4>) : ntk == 8 ? go(kw_gsum_mx<NN, 8>) : go(kw_gsum_mx<NN, 16>);
             else rc2 = ntk == 1 ? go(kw_gsum_mx<NN, 1>) : ntk == 2 ? go(kw_gsum_mx<NN, 2>)
                        : ntk == 3 ? go(kw_gsum_mx<NN, 3>) : go(kw_gsum_mx<NN, 4>);
             if (rc2) return rc2;
@@ -1137,10 +1172,12 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
 
 int wave_estep(WaveDev *r, const double *d_y, double *d_stats, hipStream_t st)
 {
-    int rc;
-    HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
-    if ((rc = wave_prepare(r, d_y, st))) return rc;
-    return wave_estep_sweeps(r, d_y, d_stats, st);
+    return wave_graphed(r, 2, d_y, d_stats, nullptr, nullptr, st, [&](hipStream_t s) -> int {
+        int rc;
+        HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), s));
+        if ((rc = wave_prepare(r, d_y, s))) return rc;
+        return wave_estep_sweeps(r, d_y, d_stats, s);
+    });
 }
 
 int wave_mstep(WaveDev *r, const double *d_stats, double *d_out, hipStream_t st)
@@ -1155,19 +1192,21 @@ int wave_mstep(WaveDev *r, const double *d_stats, double *d_out, hipStream_t st)
 // runs on the plan's second internal stream beside the forward/backward sweeps
 int wave_decode_estep(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll, double *d_stats, hipStream_t st)
 {
-    int rc;
-    HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
-    if ((rc = wave_prepare(r, d_y, st))) return rc;
-    HS_HIP(hipEventRecord(r->ev_fork, st));
-    HS_HIP(hipStreamWaitEvent(r->side2, r->ev_fork, 0));
-    // the E-step chain is the critical path: its launches are enqueued first (the dozen small launches of the
-    // decode would otherwise hold the forward sweep back by their host-side enqueue time, ~0.1 ms)
-    if ((rc = wave_estep_sweeps(r, d_y, d_stats, st))) return rc;
-    if ((rc = wave_viterbi_sweep(r, d_y, r->side2))) return rc;
-    if ((rc = wave_viterbi_post(r, d_y, d_x, d_ll, r->side2))) return rc;
-    HS_HIP(hipEventRecord(r->ev_join, r->side2));
-    HS_HIP(hipStreamWaitEvent(st, r->ev_join, 0));
-    return HMMSORT_OK;
+    return wave_graphed(r, 3, d_y, d_x, d_ll, d_stats, st, [&](hipStream_t s) -> int {
+        int rc;
+        HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), s));
+        if ((rc = wave_prepare(r, d_y, s))) return rc;
+        HS_HIP(hipEventRecord(r->ev_fork, s));
+        HS_HIP(hipStreamWaitEvent(r->side2, r->ev_fork, 0));
+        // the E-step chain is the critical path: its launches are enqueued first (the dozen small launches of the
+        // decode would otherwise hold the forward sweep back by their host-side enqueue time, ~0.1 ms)
+        if ((rc = wave_estep_sweeps(r, d_y, d_stats, s))) return rc;
+        if ((rc = wave_viterbi_sweep(r, d_y, r->side2))) return rc;
+        if ((rc = wave_viterbi_post(r, d_y, d_x, d_ll, r->side2))) return rc;
+        HS_HIP(hipEventRecord(r->ev_join, r->side2));
+        HS_HIP(hipStreamWaitEvent(s, r->ev_join, 0));
+        return HMMSORT_OK;
+    });
 }
 
 }  // namespace hmmsort

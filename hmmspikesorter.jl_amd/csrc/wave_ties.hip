@@ -95,28 +95,75 @@ __device__ __forceinline__ double tie_q(const TieChan &c, int s, int64_t t)
 // first trellis column (viterbi.jl:55-63)
 __device__ __forceinline__ double tie_base(const TieChan &c, int s) { return s == 1 ? 0.0 : tie_q(c, s, 0); }
 
-// ---- flagged decisions on the decoded path ---------------------------------------------------------
+// ---- flagged decisions on the decoded path, in time order ---------------------------------------------
+// Ordered compaction in three small kernels: flagged decisions per tile of kTieTile samples (one wavefront
+// per tile), exclusive scan over the tiles, then every tile writes its entries t * 32 + e at its offset.
+constexpr int kTieTile = 4096;
+
+__device__ __forceinline__ bool tie_flagged_at(const WaveGeom &g, const int16_t *__restrict__ xc,
+                                               const uint32_t *__restrict__ pc, int64_t planePsi, int64_t t, int *e_out)
+{
+    if (t < 2 || t >= g.T) return false;   // psi(1) only decides x[0], which kw_first_state re-decides exactly
+    const int s = xc[t];
+    int e = -1;
+    if (s == 1) e = 0;
+    else if ((s - 2) % g.L == 0) e = (s - 2) / g.L + 1;
+    if (e < 0) return false;
+    const uint32_t w = pc[(int64_t)(e / g.epw) * planePsi + t];
+    *e_out = e;
+    return ((w >> ((e % g.epw) * g.EB + g.EB - 1)) & 1u) != 0;
+}
+
+template <bool WRITE>
 __global__ __launch_bounds__(256) void kw_tie_collect(WaveGeom g, const int16_t *__restrict__ x,
                                                       const uint32_t *__restrict__ psi, int64_t *__restrict__ tie_cnt,
-                                                      int64_t *__restrict__ tie_list)
+                                                      int64_t *__restrict__ tie_off, int64_t *__restrict__ tie_list,
+                                                      int64_t ntile)
 {
     const int ch = blockIdx.y;
     if (tie_cnt[ch * 8 + kTieTrig] == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntile) return;
     const int64_t T = g.T, planePsi = (int64_t)g.C * T;
     const int16_t *xc = x + (int64_t)ch * T;
     const uint32_t *pc = psi + (int64_t)ch * T;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 2; t < T; t += (int64_t)gridDim.x * blockDim.x) {
-        const int s = xc[t];
-        int e = -1;
-        if (s == 1) e = 0;
-        else if ((s - 2) % g.L == 0) e = (s - 2) / g.L + 1;
-        if (e < 0) continue;
-        const uint32_t w = pc[(int64_t)(e / g.epw) * planePsi + t];
-        if ((w >> ((e % g.epw) * g.EB + g.EB - 1)) & 1u) {
-            const unsigned long long slot = atomicAdd((unsigned long long *)&tie_cnt[ch * 8 + kTieListed], 1ull);
-            if (slot < (unsigned long long)kTieCap) tie_list[(int64_t)ch * kTieCap + slot] = t * 32 + e;
+    int64_t *off = tie_off + (int64_t)ch * (ntile + 1);
+    int64_t run = WRITE ? off[tile] : 0;
+    for (int i = 0; i < kTieTile / 64; i++) {
+        const int64_t t = tile * kTieTile + 64 * i + lane;
+        int e = 0;
+        const bool fl = tie_flagged_at(g, xc, pc, planePsi, t, &e);
+        const unsigned long long m = __ballot(fl);
+        if (WRITE && fl) {
+            const int64_t slot = run + __popcll(m & ((1ull << lane) - 1ull));
+            if (slot < kTieCap) tie_list[(int64_t)ch * kTieCap + slot] = t * 32 + e;
         }
+        run += __popcll(m);
     }
+    if (!WRITE && lane == 0) off[tile] = run;
+}
+
+__global__ __launch_bounds__(1024) void kw_tie_offsets(const int64_t *__restrict__ tie_cnt_in, int64_t *__restrict__ tie_cnt,
+                                                       int64_t *__restrict__ tie_off, int64_t ntile)
+{
+    __shared__ int64_t part[1024];
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    if (tie_cnt_in[ch * 8 + kTieTrig] == 0) return;
+    int64_t *off = tie_off + (int64_t)ch * (ntile + 1);
+    const int64_t per = (ntile + 1023) / 1024, lo = (int64_t)tid * per, hi = lo + per < ntile ? lo + per : ntile;
+    int64_t acc = 0;
+    for (int64_t b = lo; b < hi; b++) acc += off[b];
+    part[tid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t run = 0;
+        for (int i = 0; i < 1024; i++) { const int64_t v = part[i]; part[i] = run; run += v; }
+        tie_cnt[ch * 8 + kTieListed] = run;
+    }
+    __syncthreads();
+    int64_t run = part[tid];
+    for (int64_t b = lo; b < hi; b++) { const int64_t v = off[b]; off[b] = run; run += v; }
 }
 
 // ---- approximate prefix: block sums, then their exclusive scan ---------------------------------------
@@ -546,22 +593,7 @@ __global__ __launch_bounds__(64) void kw_tie_resolve(WaveGeom g, const WaveConst
     const int n = (int)(listed < kTieCap ? listed : kTieCap);
     int64_t open = listed > kTieCap ? listed - kTieCap : 0;   // beyond the list: cannot be settled here
 
-    // time order (rank sort through the walk scratch; n is small)
-    {
-        int64_t *tmp = reinterpret_cast<int64_t *>(R.walk);
-        for (int i = lane; i < n; i += 64) {
-            const int64_t v = list[i];
-            int rank = 0;
-            for (int j = 0; j < n; j++) { const int64_t o = list[j]; rank += (o < v || (o == v && j < i)) ? 1 : 0; }
-            tmp[rank] = v;
-        }
-        __threadfence();
-        __syncthreads();
-        for (int i = lane; i < n; i += 64) list[i] = tmp[i];
-        __threadfence();
-        __syncthreads();
-    }
-
+    // the list is in time order (ordered compaction, kw_tie_collect)
     int64_t done = 0, flips = 0;
     for (int idx = 0; idx < n; idx++) {
         const int64_t t0 = list[idx] >> 5;
@@ -720,8 +752,11 @@ int wave_tie_resolve(WaveDev *r, const double *d_y, int16_t *d_x, hipStream_t st
     const WaveGeom &g = r->g;
     const int64_t nblk = r->tie_nblk;
     { WPROF(r, "kw_tie_collect", st);
-      const unsigned nb = (unsigned)std::min<int64_t>((g.T + 2047) / 2048, 2048);
-      hipLaunchKernelGGL(kw_tie_collect, dim3(nb, g.C), dim3(256), 0, st, g, d_x, r->psi, r->tie_cnt, r->tie_list); }
+      const int64_t ntile = r->tie_ntile;
+      const dim3 gt((unsigned)((ntile + 3) / 4), g.C);
+      hipLaunchKernelGGL(kw_tie_collect<false>, gt, dim3(256), 0, st, g, d_x, r->psi, r->tie_cnt, r->tie_off, r->tie_list, ntile);
+      hipLaunchKernelGGL(kw_tie_offsets, dim3(g.C), dim3(1024), 0, st, r->tie_cnt, r->tie_cnt, r->tie_off, ntile);
+      hipLaunchKernelGGL(kw_tie_collect<true>, gt, dim3(256), 0, st, g, d_x, r->psi, r->tie_cnt, r->tie_off, r->tie_list, ntile); }
     { WPROF(r, "kw_tie_prefix", st);
       hipLaunchKernelGGL(kw_tie_bsum, dim3((unsigned)((nblk + 3) / 4), g.C), dim3(256), 0, st, g, r->d_cst, d_y, d_x,
                          r->d_mean, r->d_ctab, r->tie_cnt, r->tie_guess, nblk);

@@ -829,11 +829,13 @@ int wave_viterbi_post(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll,
 
 int wave_viterbi(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st)
 {
-    int rc;
-    HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), st));
-    if ((rc = wave_prepare(r, d_y, st))) return rc;
-    if ((rc = wave_viterbi_sweep(r, d_y, st))) return rc;
-    return wave_viterbi_post(r, d_y, d_x, d_ll, st);
+    return wave_graphed(r, 1, d_y, d_x, d_ll, nullptr, st, [&](hipStream_t s) -> int {
+        int rc;
+        HS_HIP(hipMemsetAsync(r->diag, 0, 8 * sizeof(int64_t), s));
+        if ((rc = wave_prepare(r, d_y, s))) return rc;
+        if ((rc = wave_viterbi_sweep(r, d_y, s))) return rc;
+        return wave_viterbi_post(r, d_y, d_x, d_ll, s);
+    });
 }
 
 }  // namespace hmmsort

@@ -27,6 +27,29 @@ def time_shard(T, rank, world_size, halo):
     return s_lo, s_hi, lo - s_lo, hi - s_lo, first, last
 
 
+def time_shard_plan(y, rank, world_size, lA, mu, sigma, halo=2048):
+    """Plan + slice of recording `y` for `rank` with shard edges that carry a certificate: the wave engine
+    certifies every chain boundary (a warm-up started from "silent, rings empty" against the neighbouring
+    chain's own sweep), and a boundary inside each halo is what shows that the slice's arbitrary ends have
+    been forgotten where the owned range begins (hmmsort_plan_set_shard refuses a shard without one).  The
+    halo is widened until the plan's chain length fits into it.  Returns (plan, y_slice, (own_lo, own_hi))."""
+    from . import _lib
+    from .device import Plan
+    T = len(y)
+    for _ in range(8):
+        s_lo, s_hi, o_lo, o_hi, first, last = time_shard(T, rank, world_size, halo)
+        ys = np.ascontiguousarray(y[s_lo:s_hi])
+        plan = Plan(len(ys), lA, mu, sigma)
+        try:
+            plan.set_shard(o_lo, o_hi, first, last)
+            return plan, ys, (o_lo, o_hi)
+        except _lib.HmmsortError:
+            block = plan.info()["block"]
+            plan.close()
+            halo = max(2 * halo, 2 * block + 64)
+    raise RuntimeError("time_shard_plan: no halo up to %d samples holds a chain boundary" % halo)
+
+
 def allreduce_stats(stats, group=None):
     """In-place SUM all-reduce of a statistics vector (torch tensor on the rank's device)."""
     import torch.distributed as dist

@@ -10,7 +10,7 @@ read side is doubled (calibration: kw_prepass reads y once and writes N ring-sco
 _meta.kernel_sources = sha256 over hmmspikesorter.jl_amd/csrc/*.{hip,h,cpp}: bench.py only quotes
 the counters of a summary whose hash equals that of the sources it runs.
 
-usage: summarize.py <tag> <raw dir with trace/ pmc_fetch/ pmc_write/ [pmc_sq/]> [samples block halo]
+usage: summarize.py <tag> <raw dir with trace/ pmc_fetch/ pmc_write/ [pmc_sq/]> [samples block halo [neurons states channels]]
 """
 import collections
 import csv
@@ -87,6 +87,8 @@ def main():
             "command": "scripts/profile_bench.sh %s (python3 bench.py --quick --steps 5 --warmup 2 ...)" % tag}
     if len(sys.argv) >= 6:
         meta.update(samples=int(sys.argv[3]), block=int(sys.argv[4]), halo=int(sys.argv[5]))
+    if len(sys.argv) >= 9:   # model shape and channels per plan (default: the headline's 4 x 60, one channel)
+        meta.update(neurons=int(sys.argv[6]), states=int(sys.argv[7]), channels=int(sys.argv[8]))
     out["_meta"] = meta
     json.dump(out, open(os.path.join(HERE, tag + "_summary.json"), "w"), indent=1)
     with open(os.path.join(HERE, tag + "_summary.md"), "w") as f:

@@ -76,6 +76,43 @@ def test_two_host_threads_decode_concurrently(H):
         assert np.array_equal(x, x0) and ll == ll0
 
 
+def test_two_host_threads_overlap_on_the_device(H):
+    # every host-buffer call works on its slot's own stream and waits for that stream only (no
+    # hipDeviceSynchronize): two threads decoding 10 M samples each take clearly less than twice one thread
+    import time
+    temps, pp, sm = model(H)
+    T = 10_000_000
+    ys = [H.create_signal(T, 0.3, pp, temps, seed=70 + i) for i in range(2)]
+    for y in ys:                       # warm: plans and buffers of both slots exist
+        H.viterbi(y, sm, temps, 0.3)
+    th = [threading.Thread(target=H.viterbi, args=(ys[i], sm, temps, 0.3)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]             # now two slots are cached
+
+    def one(n):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            H.viterbi(ys[0], sm, temps, 0.3)
+        return (time.perf_counter() - t0) / n
+
+    def two(n):
+        def w(i):
+            for _ in range(n):
+                H.viterbi(ys[i], sm, temps, 0.3)
+        t0 = time.perf_counter()
+        tt = [threading.Thread(target=w, args=(i,)) for i in range(2)]
+        [t.start() for t in tt]
+        [t.join() for t in tt]
+        return (time.perf_counter() - t0) / n
+
+    t1 = min(one(5), one(5))
+    t2 = min(two(5), two(5))
+    print("host-buffer decode of 10 M samples: one thread %.2f ms, two threads %.2f ms per round (%.2fx)"
+          % (t1 * 1e3, t2 * 1e3, t2 / t1))
+    H.shutdown()
+    assert t2 < 1.5 * t1, (t1, t2)
+
+
 def test_shutdown_frees_the_cached_buffers_and_em_step_is_cheap_when_cached(H):
     import torch
     temps, pp, sm = model(H)

@@ -95,12 +95,21 @@ def test_exit_to_entry_values_that_depend_on_the_source_ring(O, H, N, K, T, seed
     # busy enough that spikes follow each other directly (the exit -> entry transitions are on the paths)
     pp = rng.uniform(0.004, 0.012, N) * min(1.0, 4.0 / N)
     y = H.create_signal(T, 0.3, pp, temps, seed=seed)
+    # the generator never lets spikes abut (it races only while silent): add pairs that do, so that the decoded
+    # paths take exit -> entry transitions (a,L) -> (b,1)
+    L = K - 1
+    for i in range(12):
+        t0 = 2000 + i * (T - 4000) // 12
+        a, b = i % N, (i + 1 + i // N) % N
+        if a == b:
+            b = (b + 1) % N
+        y[t0:t0 + L] += 1.5 * temps[1:, a]
+        y[t0 + L:t0 + 2 * L] += 1.5 * temps[1:, b]
     sm = _per_source_list(H, H.StateMatrix.create(N, K, np.log(pp), False), N, K, rng)
     osm = to_oracle_sm(O, sm)
     x, ll = H.viterbi(y, sm, temps, 0.3)
     xo, llo = O.viterbi(y, osm, temps, 0.3)
     # the paths do use ring -> ring transitions
-    L = K - 1
     direct = np.count_nonzero((xo[:-1] > 1) & ((xo[:-1] - 2) % L == L - 1) & (xo[1:] > 1))
     assert direct > 3, direct
     assert np.array_equal(x, xo), int(np.count_nonzero(x != xo))

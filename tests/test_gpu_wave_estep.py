@@ -202,13 +202,21 @@ def test_time_sharded_estep_equals_whole_recording(O, H):
     total = torch.zeros_like(ref)
     world = 3
     for rank in range(world):
-        s_lo, s_hi, o_lo, o_hi, first, last = H.dist.time_shard(T, rank, world, halo=1024)
-        plan = H.Plan(s_hi - s_lo, sm, mu, 0.35)
-        plan.set_shard(o_lo, o_hi, first, last)
+        # shard edges carry a certificate: a certified chain boundary lies inside each halo
+        plan, ys, (o_lo, o_hi) = H.dist.time_shard_plan(y, rank, world, sm, mu, 0.35, halo=256)
+        assert plan.info()["block"] <= o_lo or rank == 0
         part = torch.zeros_like(ref)
-        plan.estep(dy[s_lo:s_hi].contiguous(), part, st)
+        plan.estep(torch.from_numpy(ys).cuda(), part, st)
+        d = plan.diagnostics(st)
+        assert d[3] == 0 and d[5] == 0 and max(d[4], d[6]) < 1e-9, d
         total += part
         plan.close()
+    # a shard whose halo is shorter than a chain has no certified boundary in front of its owned range: refused
+    s_lo, s_hi, o_lo, o_hi, first, last = H.dist.time_shard(T, 1, world, halo=64)
+    short = H.Plan(s_hi - s_lo, sm, mu, 0.35)
+    with pytest.raises(H.HmmsortError):
+        short.set_shard(o_lo, o_hi, first, last)
+    short.close()
     torch.cuda.synchronize()
     r, t = ref.cpu().numpy(), total.cpu().numpy()
     assert np.allclose(t, r, rtol=1e-9, atol=1e-12), np.abs(t - r).max()
@@ -241,12 +249,15 @@ def test_train_model_loop_stays_on_device(O, H):
     assert np.allclose(sm_n.transitions["lp"], osm.val, rtol=1e-8, atol=1e-12)
 
 
-@pytest.mark.parametrize("N,K,T", [(4, 60, 300_000), (3, 17, 50_001), (4, 65, 120_000)])
+@pytest.mark.parametrize("N,K,T", [(4, 60, 300_000), (3, 17, 50_001), (4, 65, 120_000),
+                                   (8, 128, 200_000), (5, 50, 90_001), (8, 65, 100_000), (6, 100, 120_000), (7, 129, 150_000)])
 def test_fused_statistics_equal_the_separate_kernel(H, N, K, T, monkeypatch):
-    # 3-4 rings of at most 64 states: the backward sweep accumulates the spike-triggered sums itself (matrix
-    # cores, LDS rings); HMMSORT_GSUM_SEPARATE forces the stand-alone statistics kernel on the same posteriors
-    temps = np.asfortranarray(np.stack([H.create_spike_template(K, 2.5 + 0.5 * i, 0.3 + 0.15 * i, 0.2) for i in range(N)], 1))
-    pp = [0.003, 0.001, 0.002, 0.0015][:N]
+    # 3-4 rings of at most 64 states, 5-8 rings of at most 128 (BASELINE config 4's shape: two / four accumulator
+    # tiles of 32 lags): the backward sweep accumulates the spike-triggered sums itself (matrix cores, LDS rings);
+    # HMMSORT_GSUM_SEPARATE forces the stand-alone statistics kernel on the same posteriors
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, 2.5 + 0.3 * i, 0.3 + 0.08 * i, 0.2) for i in range(N)], 1))
+    pp = ([0.003, 0.001, 0.002, 0.0015] * 2)[:N]
+    pp = [p * min(1.0, 60.0 / K) for p in pp]
     sm = H.StateMatrix.create(N, K, np.log(pp), False)
     y = H.create_signal(T, 0.3, pp, temps, seed=N * K)
     mu0 = np.asfortranarray(temps * 0.9)
