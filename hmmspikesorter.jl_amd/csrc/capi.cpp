@@ -202,7 +202,9 @@ int plan_create_engine(hmmsort_plan **out, int64_t T, const int16_t *states, int
         set_error("ring engine unavailable for this model/signal: %s", why.c_str());
         return HMMSORT_EUNSUP;
     }
-    const bool want_ring = engine_req == HMMSORT_ENGINE_AUTO || engine_req == HMMSORT_ENGINE_RING;
+    // the round-1 lane-per-chain engine is kept as a second implementation for cross-checks only: AUTO never
+    // picks it (what the wave engine does not take goes to the blocked / strict engines, which take any list)
+    const bool want_ring = engine_req == HMMSORT_ENGINE_RING;
     if ((engine_req == HMMSORT_ENGINE_AUTO || engine_req == HMMSORT_ENGINE_WAVE) && wave_ok) {
         p->engine = HMMSORT_ENGINE_WAVE;
         p->models.assign(1, p->model);

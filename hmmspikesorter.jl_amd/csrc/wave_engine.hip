@@ -14,11 +14,36 @@ static inline int64_t wround_up(int64_t v, int64_t m) { return (v + m - 1) / m *
 
 constexpr int64_t kWaveLdsMax = 160 * 1024;
 
+// exit -> entry log-probabilities (b,L) -> (a,1) independent of the source ring b, bit for bit: true for every
+// list the reference builds (types.jl:94-113)
+static bool ring_uniform_cx(const RingModel &R)
+{
+    const int N = R.N;
+    for (int a = 0; a < N; a++) {
+        double ref = 0.0;
+        bool have = false;
+        for (int b = 0; b < N; b++) {
+            if (b == a) continue;
+            const double v = R.cx[b * N + a];
+            if (!have) { ref = v; have = true; }
+            else if (!(v == ref)) return false;
+        }
+    }
+    return true;
+}
+
+// per-source exit -> entry values take the O(N^2) junction code, which is built for up to kWaveMaxPerSource rings
+// (with 12-13 rings of fewer than 32 states those kernels -- 200+ spilled scalar registers -- gave wrong forward
+// values on gfx950, found by tests/test_gpu_wave_edges.py; such lists go to the blocked / strict engines)
+constexpr int kWaveMaxPerSource = 8;
+
 bool wave_supported(const HostModel &m, int64_t T, std::string *why)
 {
     auto no = [&](const char *w) { if (why) *why = w; return false; };
     if (!m.ring.valid) return no("transition list is not the no-overlap ring pattern");
     if (m.ring.N > kRingMaxN) return no("more than 16 rings");
+    if (m.ring.N > kWaveMaxPerSource && !ring_uniform_cx(m.ring))
+        return no("exit->entry log-probabilities depend on the source ring and there are more than 8 rings");
     if (m.ring.L < 8) return no("rings shorter than 8 states");
     if (T < 4 * (int64_t)m.ring.L || T < 512) return no("signal shorter than 4 ring lengths / 512 samples");
     const int W = std::min(m.ring.L, 64);
@@ -89,6 +114,8 @@ int wave_set_model(WaveDev *r, int ch, const HostModel &m)
     HS_CHECK(ch >= 0 && ch < g.C, HMMSORT_EINVAL, "wave set_model: channel %d outside 0..%d", ch, g.C - 1);
     HS_CHECK(m.ring.valid && m.ring.N == g.N && m.ring.L == g.L && m.S == r->S, HMMSORT_EINVAL,
              "wave set_model: model shape changed");
+    HS_CHECK(g.N <= kWaveMaxPerSource || ring_uniform_cx(m.ring), HMMSORT_EUNSUP,
+             "wave set_model: exit->entry log-probabilities depend on the source ring and there are more than 8 rings");
     r->bound_y = nullptr;
     r->ring[ch] = m.ring;
     r->mean[ch] = m.mean;

@@ -301,6 +301,10 @@ struct BIn {
     double fref, la0; // fref(t+1), la0(t)
 };
 
+// y ring of the fused statistics: the product reads back to the largest lag (+ 18) behind tau, tau trails the
+// write head by up to 72 steps and a step writes 64 entries ahead: 64 lags -> 202 entries, 128 lags -> 266
+constexpr int bwd_yring(int ft) { return ft <= 2 ? 256 : 512; }
+
 // FT > 0 (fused statistics; 3-4 rings of at most 64 states: FT = 1; 5-8 rings of at most 64 / 128 states: FT = 2 / 4):
 // the spike-triggered sums G1[a][lag] = sum_t' rho_a(t') y(t' + lag) are accumulated by the sweep itself on the
 // matrix cores, so rho is not read back by a statistics kernel.  The sweep runs backward in time; with
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
     constexpr int NPc = N <= 4 ? 4 : 8, NSc = 16 / NPc, LPT = 16 * NSc;   // ring columns per copy, copies, lags per tile
     constexpr int RPAD = NPc == 4 ? 1 : 2;                   // padding rows per 16 rows of the rho ring (bank spread of the copies)
     constexpr int RGROWS = 128 + 8 * RPAD;
-    constexpr int YM = (FT * LPT + 16 * (NSc - 1) + 160) <= 256 ? 256 : 512;   // y ring: largest lag + step width + slack
+    constexpr int YM = bwd_yring(FT);                        // y ring: largest lag + two step widths + slack
     constexpr int NACC = FT <= 1 ? 2 : FT;                   // FT = 1: two tiles alternate (independent MFMA chains)
     constexpr int D = N <= 4 ? 3 : (N <= 8 ? 2 : 1);   // input pipeline depth in super-steps (4 with the fused statistics: spills, 0.70 ms)
     constexpr int KSC = 4, KCP0 = 4 + N, KPEND = 4 + 2 * N, KCPX = 4 + 3 * N, KSIZE = 4 + 3 * N + N * N;
@@ -1095,11 +1099,14 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
         const int ft = sep ? 0 : (kFuse4 && L <= 64) ? 1 : (kFuse8 && r->uniform_cx && L <= 64) ? 2
                        : (kFuse8 && r->uniform_cx && L <= 128) ? 4 : 0;
         const bool fuse = ft > 0;
-        const int ym = ft <= 1 ? 256 : ((ft * 32 + 16 + 160) <= 256 ? 256 : 512);
+        const int ym = bwd_yring(ft);
         const size_t ldsb = ((size_t)(NN + 1) * (g.RB + 1) + 4 + 3 * NN + NN * NN +
                              (fuse ? ym + (128 + 8 * (NN <= 4 ? 1 : 2)) * (NN <= 4 ? 4 : 8) : 0)) * sizeof(double);
-        auto kf = r->uniform_cx ? kw_fwd<NN, true> : kw_fwd<NN, false>;
-        auto kb = r->uniform_cx ? kw_bwd<NN, true> : kw_bwd<NN, false>;
+        auto kf = kw_fwd<NN, true>;
+        auto kb = kw_bwd<NN, true>;
+        if constexpr (NN <= 8) {   // per-source exit -> entry values: up to 8 rings (wave_supported)
+            if (!r->uniform_cx) { kf = kw_fwd<NN, false>; kb = kw_bwd<NN, false>; }
+        }
         if constexpr (kFuse4) {
             if (ft == 1) kb = r->uniform_cx ? kw_bwd<NN, true, 1> : kw_bwd<NN, false, 1>;
         }
@@ -1131,10 +1138,12 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
         if (fuse) {
             rowsG = g.nch;                      // partG[ch][chain][N L], written by kw_bwd
         } else if (!generic) {
-            // up to 4 accumulator tiles per workgroup for N <= 8 (longer rings take one pass over rho per group of
-            // 4); more than 8 rings (16 lags per tile): 8 or 16 tiles, so that rings of up to 255 states need ONE
-            // pass over rho instead of four (config 5's shape: 128 B of posteriors per sample and pass)
-            const int ntk = NN > 8 ? (ntx <= 4 ? 4 : (ntx <= 8 ? 8 : 16)) : (ntx < 4 ? ntx : 4), ngrp = (ntx + ntk - 1) / ntk;
+            // up to 4 accumulator tiles per workgroup (longer rings take one pass over rho per group of 4); with more
+            // than 8 rings (16 lags per tile) 8 or 16 tiles per workgroup can be asked for (HMMSORT_GSUM_TILES)
+            // (measured at N = 16, L = 255, 40 M samples: 4 tiles and four passes 9.0 ms, 16 tiles and one pass 10.2 ms --
+            // the kernel is bound by its matrix-core issue at one wave per SIMD, not by the re-reads of rho)
+            static const int nt_big = getenv("HMMSORT_GSUM_TILES") ? atoi(getenv("HMMSORT_GSUM_TILES")) : 4;
+            const int ntk = NN > 8 ? (nt_big >= 16 ? 16 : (nt_big >= 8 ? 8 : 4)) : (ntx < 4 ? ntx : 4), ngrp = (ntx + ntk - 1) / ntk;
             rowsG = (int)((g.T + kGxSubs * 8 * (int64_t)kGxBv - 1) / (kGxSubs * 8 * (int64_t)kGxBv));
             constexpr int RRx = kGxTR + HSx, RRPx = RRx + RRx / 16 + 1;
             const size_t l1 = ((size_t)8 * (RRPx * NPx + 2) + (size_t)8 * (kGxTR + 19 + LPTx * (ntk - 1))) * 8;

@@ -758,7 +758,8 @@ int wave_viterbi_sweep(WaveDev *r, const double *d_y, hipStream_t st)
     return dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
         const size_t lds = ((size_t)N * (g.RB + 1) + 3 + 2 * N + N * N) * sizeof(double);
-        auto kern = r->uniform_cx ? kw_vit<N, true> : kw_vit<N, false>;
+        auto kern = kw_vit<N, true>;
+        if constexpr (N <= 8) { if (!r->uniform_cx) kern = kw_vit<N, false>; }   // per-source values: up to 8 rings (wave_supported)
         int rc = wave_lds_attr(kern, lds);
         if (rc) return rc;
         { WPROF(r, "kw_vit", st);
@@ -777,7 +778,8 @@ int wave_viterbi_post(WaveDev *r, const double *d_y, int16_t *d_x, double *d_ll,
     int rc = dispatch_N(g.N, [&](auto n) {
         constexpr int N = decltype(n)::value;
         const size_t lds = ((size_t)N * (g.RB + 1) + 3 + 2 * N + N * N) * sizeof(double);
-        auto kern = r->uniform_cx ? kw_vit<N, true> : kw_vit<N, false>;
+        auto kern = kw_vit<N, true>;
+        if constexpr (N <= 8) { if (!r->uniform_cx) kern = kw_vit<N, false>; }   // per-source values: up to 8 rings (wave_supported)
         for (int round = 0; round < kVitRounds && g.nch > 1; round++) {
             { WPROF(r, "kw_vit_check", st);
               hipLaunchKernelGGL(kw_vit_check, dim3(nchT), dim3(64), 0, st, g, r->vpre, r->vend, r->vfail, r->diag, 0, nullptr); }

@@ -78,39 +78,44 @@ def test_two_host_threads_decode_concurrently(H):
 
 def test_two_host_threads_overlap_on_the_device(H):
     # every host-buffer call works on its slot's own stream and waits for that stream only (no
-    # hipDeviceSynchronize): two threads decoding 10 M samples each take clearly less than twice one thread
+    # hipDeviceSynchronize): two threads decoding 10 M samples each take clearly less than twice one thread.
+    # What cannot overlap is the PCIe link both share: a float64 recording moves 100 MB per call (80 up, 20
+    # down: 1.75 of the 2.9 ms), the acquisition's own int16 samples (src/hmmsort.jl:79-88) 40 MB.
     import time
     temps, pp, sm = model(H)
     T = 10_000_000
     ys = [H.create_signal(T, 0.3, pp, temps, seed=70 + i) for i in range(2)]
-    for y in ys:                       # warm: plans and buffers of both slots exist
-        H.viterbi(y, sm, temps, 0.3)
-    th = [threading.Thread(target=H.viterbi, args=(ys[i], sm, temps, 0.3)) for i in range(2)]
-    [t.start() for t in th]
-    [t.join() for t in th]             # now two slots are cached
+    raws = [np.round(y * 1000.0).astype(np.int16) for y in ys]       # microvolt-like integer samples
+    cases = {"float64": (ys, temps, 0.3, 1.75), "int16": (raws, np.asfortranarray(temps * 1000.0), 300.0, 1.5)}
+    for name, (sig, tm, sg, bound) in cases.items():
+        for y in sig:                      # warm: plans and buffers of both slots exist
+            H.viterbi(y, sm, tm, sg)
+        th = [threading.Thread(target=H.viterbi, args=(sig[i], sm, tm, sg)) for i in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]             # now two slots are cached
 
-    def one(n):
-        t0 = time.perf_counter()
-        for _ in range(n):
-            H.viterbi(ys[0], sm, temps, 0.3)
-        return (time.perf_counter() - t0) / n
-
-    def two(n):
-        def w(i):
+        def one(n):
+            t0 = time.perf_counter()
             for _ in range(n):
-                H.viterbi(ys[i], sm, temps, 0.3)
-        t0 = time.perf_counter()
-        tt = [threading.Thread(target=w, args=(i,)) for i in range(2)]
-        [t.start() for t in tt]
-        [t.join() for t in tt]
-        return (time.perf_counter() - t0) / n
+                H.viterbi(sig[0], sm, tm, sg)
+            return (time.perf_counter() - t0) / n
 
-    t1 = min(one(5), one(5))
-    t2 = min(two(5), two(5))
-    print("host-buffer decode of 10 M samples: one thread %.2f ms, two threads %.2f ms per round (%.2fx)"
-          % (t1 * 1e3, t2 * 1e3, t2 / t1))
-    H.shutdown()
-    assert t2 < 1.5 * t1, (t1, t2)
+        def two(n):
+            def w(i):
+                for _ in range(n):
+                    H.viterbi(sig[i], sm, tm, sg)
+            t0 = time.perf_counter()
+            tt = [threading.Thread(target=w, args=(i,)) for i in range(2)]
+            [t.start() for t in tt]
+            [t.join() for t in tt]
+            return (time.perf_counter() - t0) / n
+
+        t1 = min(one(5), one(5))
+        t2 = min(two(5), two(5))
+        print("host-buffer decode of 10 M %s samples: one thread %.2f ms, two threads %.2f ms per round (%.2fx)"
+              % (name, t1 * 1e3, t2 * 1e3, t2 / t1))
+        H.shutdown()
+        assert t2 < bound * t1, (name, t1, t2)
 
 
 def test_shutdown_frees_the_cached_buffers_and_em_step_is_cheap_when_cached(H):

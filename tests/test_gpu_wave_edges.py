@@ -85,7 +85,8 @@ def _per_source_list(H, sm, N, K, rng):
     return H.StateMatrix(sm.states, tr, sm.pi, sm.K, sm.N, sm.nstates, False)
 
 
-@pytest.mark.parametrize("N,K,T,seed", [(4, 60, 150_000, 1), (3, 30, 40_000, 2), (8, 40, 60_000, 3), (12, 24, 50_000, 4)])
+@pytest.mark.parametrize("N,K,T,seed", [(4, 60, 150_000, 1), (3, 30, 40_000, 2), (8, 40, 60_000, 3), (8, 24, 30_000, 5),
+                                        (6, 20, 30_000, 6), (12, 24, 50_000, 4), (13, 24, 30_000, 7)])
 def test_exit_to_entry_values_that_depend_on_the_source_ring(O, H, N, K, T, seed):
     rng = np.random.default_rng(seed)
     base = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)]
@@ -107,6 +108,12 @@ def test_exit_to_entry_values_that_depend_on_the_source_ring(O, H, N, K, T, seed
         y[t0 + L:t0 + 2 * L] += 1.5 * temps[1:, b]
     sm = _per_source_list(H, H.StateMatrix.create(N, K, np.log(pp), False), N, K, rng)
     osm = to_oracle_sm(O, sm)
+    if N > 8:
+        # the wave engine's per-source junction code is built for up to 8 rings: such a list is refused by the
+        # wave engine and AUTO hands it to the blocked engine (any transition list)
+        with pytest.raises(H.HmmsortError):
+            H.viterbi(y, sm, temps, 0.3)
+        H.set_option("engine", H.ENGINE_AUTO)
     x, ll = H.viterbi(y, sm, temps, 0.3)
     xo, llo = O.viterbi(y, osm, temps, 0.3)
     # the paths do use ring -> ring transitions
