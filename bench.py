@@ -267,7 +267,8 @@ def run_config45(args, torch, H, dist, world, rank, dev):
                                       "statistics of all channels summed by ONE all-reduce per step (pooled templates: "
                                       "extension)" if args.pooled else "per-channel models (no collective)"),
                        "channels": total, "channels_per_rank": len(mine), "samples_per_channel": T, "states": S,
-                       "engine": "wave", "block": info["block"] if info else None, "seed": 1234,
+                       "engine": "wave", "block": info["block"] if info else None,
+                       "halo": info["halo"] if info else None, "seed": 1234,
                        "pooled_allreduce": bool(args.pooled)},
             "roofline": roof,
             "detail": {"boundary_check_fails": bad[:3], "near_ties_unresolved": bad[3], "near_ties_resolved_rank0": ties_done,

@@ -337,7 +337,10 @@ __global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const W
     constexpr int RGROWS = 128 + 8 * RPAD;
     constexpr int YM = bwd_yring(FT);                        // y ring: largest lag + two step widths + slack
     constexpr int NACC = FT <= 1 ? 2 : FT;                   // FT = 1: two tiles alternate (independent MFMA chains)
-    constexpr int D = N <= 4 ? 3 : (N <= 8 ? 2 : 1);   // input pipeline depth in super-steps (4 with the fused statistics: spills, 0.70 ms)
+#ifndef HS_BWD_D4
+#define HS_BWD_D4 2
+#endif
+    constexpr int D = N <= 4 ? HS_BWD_D4 : (N <= 8 ? 2 : 1);   // input pipeline depth in super-steps (N <= 4: 3 leaves 4 spilled registers and runs 2 % slower, 4 spills heavily: 0.70 ms)
     constexpr int KSC = 4, KCP0 = 4 + N, KPEND = 4 + 2 * N, KCPX = 4 + 3 * N, KSIZE = 4 + 3 * N + N * N;
     extern __shared__ double lds[];
     const int L = g.L, W = g.W, RB = g.RB, B = g.B;
