@@ -89,8 +89,19 @@ def measured_traffic(T, block, N=4, K=60, channels=1):
         if (meta.get("kernel_sources") == want and meta.get("samples") == T and meta.get("block") == block and
                 meta.get("neurons", 4) == N and meta.get("states", 60) == K and meta.get("channels", 1) == channels):
             measured_traffic.raw = d
-            return {k: v["hbm_read_bytes"] + v["hbm_write_bytes"] for k, v in d.items() if k != "_meta"}, \
-                os.path.basename(path)
+            out = {k: v["hbm_read_bytes"] + v["hbm_write_bytes"] for k, v in d.items() if k != "_meta"}
+            # the library's timing brackets name launch groups; rocprofv3 names kernels
+            for alias, names in (("kw_gsum", ("kw_gsum_mx", "kw_gsum_generic")),
+                                 ("kw_tie_prefix", ("kw_tie_bsum", "kw_tie_bscan", "kw_tie_btransfer")),
+                                 ("kw_stitch_fix", ("kw_stitch_fix_par", "kw_stitch_fix"))):
+                if alias not in out or alias == "kw_stitch_fix":
+                    vals = [out[n] for n in names if n in out]
+                    if vals:
+                        out[alias] = sum(vals)
+            for k, v in list(d.items()):
+                if k != "_meta" and k in ("kw_gsum_mx",) and "kw_gsum" not in d:
+                    d["kw_gsum"] = v
+            return out, os.path.basename(path)
     return None, None
 
 

@@ -1141,12 +1141,15 @@ static int wave_estep_sweeps(WaveDev *r, const double *d_y, double *d_stats, hip
         if (fuse) {
             rowsG = g.nch;                      // partG[ch][chain][N L], written by kw_bwd
         } else if (!generic) {
-            // up to 4 accumulator tiles per workgroup (longer rings take one pass over rho per group of 4); with more
-            // than 8 rings (16 lags per tile) 8 or 16 tiles per workgroup can be asked for (HMMSORT_GSUM_TILES)
-            // (measured at N = 16, L = 255, 40 M samples: 4 tiles and four passes 9.0 ms, 16 tiles and one pass 10.2 ms --
-            // the kernel is bound by its matrix-core issue at one wave per SIMD, not by the re-reads of rho)
-            static const int nt_big = getenv("HMMSORT_GSUM_TILES") ? atoi(getenv("HMMSORT_GSUM_TILES")) : 4;
-            const int ntk = NN > 8 ? (nt_big >= 16 ? 16 : (nt_big >= 8 ? 8 : 4)) : (ntx < 4 ? ntx : 4), ngrp = (ntx + ntk - 1) / ntk;
+            // up to 4 accumulator tiles per workgroup for N <= 8 (longer rings take one pass over rho per group of 4);
+            // more than 8 rings (16 lags per tile): up to 16 tiles, so that rings of up to 255 states need ONE pass
+            // over rho (128 B of posteriors per sample and pass at N = 16); HMMSORT_GSUM_TILES = 4 / 8 / 16: tuning aid
+            // (measured at N = 16, L = 255, 40 M samples: 4 tiles and four passes over rho 12.3 ms and 22 GB of HBM
+            // traffic, 16 tiles and one pass 10.2 ms)
+            static const int nt_big = getenv("HMMSORT_GSUM_TILES") ? atoi(getenv("HMMSORT_GSUM_TILES")) : 16;
+            const int want = nt_big >= 16 ? 16 : (nt_big >= 8 ? 8 : 4);
+            const int ntk = NN > 8 ? (ntx <= 4 ? 4 : (ntx <= 8 ? (want < 8 ? want : 8) : want)) : (ntx < 4 ? ntx : 4);
+            const int ngrp = (ntx + ntk - 1) / ntk;
             rowsG = (int)((g.T + kGxSubs * 8 * (int64_t)kGxBv - 1) / (kGxSubs * 8 * (int64_t)kGxBv));
             constexpr int RRx = kGxTR + HSx, RRPx = RRx + RRx / 16 + 1;
             const size_t l1 = ((size_t)8 * (RRPx * NPx + 2) + (size_t)8 * (kGxTR + 19 + LPTx * (ntk - 1))) * 8;

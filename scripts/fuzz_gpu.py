@@ -27,6 +27,9 @@ def run(n_cases, seed, verbose=True):
 STRESS = bool(int(__import__("os").environ.get("FUZZ_STRESS", "0")))  # bigger, busier models
 TIES = bool(int(__import__("os").environ.get("FUZZ_TIES", "0")))     # duplicate templates: tie-breaking rules
 ENGINE = int(__import__("os").environ.get("FUZZ_ENGINE", "0"))        # 0 auto, 1 strict, 3 blocked (decode)
+TIESCALE = bool(int(__import__("os").environ.get("FUZZ_TIESCALE", "0")))  # random multipliers of the wave engine's near-tie
+#   threshold: ordinary decisions get flagged and the exact resolver (wave_ties.hip) has to re-decide them to the oracle's answer
+PERSRC = bool(int(__import__("os").environ.get("FUZZ_PERSRC", "0")))      # exit->entry log-probabilities that depend on the source ring
 
 
 def one_case(rng, case):
@@ -48,7 +51,16 @@ def one_case(rng, case):
                 temps[:, 3] = temps[:, 2]; pp[3] = pp[2]
         y = H.create_signal(T, sigma, pp, temps, seed=int(rng.integers(1, 1 << 30)))
         sm = H.StateMatrix.create(N, K, np.log(pp), ov)
+        if PERSRC and not ov and N >= 2 and rng.random() < 0.7:
+            L_ = K - 1
+            tr = sm.transitions.copy()
+            for i_ in range(len(tr)):
+                s_, d_ = int(tr["src"][i_]), int(tr["dst"][i_])
+                if s_ > 1 and d_ > 1 and (s_ - 2) % L_ == L_ - 1 and (d_ - 2) % L_ == 0:
+                    tr["lp"][i_] += rng.uniform(-0.5, 0.5)
+            sm = H.StateMatrix(sm.states, tr, sm.pi, sm.K, sm.N, sm.nstates, False)
         osm = to_oracle_sm(O, sm)
+        H.set_option("tie_scale", int(rng.choice([1, 1, 10 ** 6, 10 ** 8, 10 ** 9])) if TIESCALE else 1)
         blk = int(rng.choice([0, 0, 128, 192, 256, 512, 1024]))   # geometry requests: the engines clamp
         hal = int(rng.choice([0, 0, 64, 128, 256, 512]))          # them; a short warm-up must escalate
         H.set_option("block", blk)
@@ -92,6 +104,7 @@ def one_case(rng, case):
             ok, msg = False, "EXCEPTION %r" % (exc,)
         H.set_option("block", 0)
         H.set_option("halo", 0)
+        H.set_option("tie_scale", 1)
     return ok, tag, msg
 
 
