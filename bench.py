@@ -132,7 +132,10 @@ def shape_roofline(plan, info, N, K, T, channels, step_s, stream, profiled_step)
     step_counters = sum(counters.get(k, 0.0) * prof[k][1] for k in ksum) if counters else None
     step_model = sum(model.values())
     return {"bound": bound, "kernel": dom, "achieved": achieved, "peak": peak, "unit": unit,
-            "frac": (achieved / peak) if achieved else None, "traffic": dom_counter,
+            "frac": (achieved / peak) if achieved else None,
+            # fp64 v_mfma_f64_16x16x4 sustained on this box (scripts/micro/mfma_probe.hip): 36 TFLOP/s at one wave per
+            # SIMD, 47 from two waves up -- below the spec figure used as `peak`
+            "peak_measured": 47.0 if bound == "mfma" else None, "traffic": dom_counter,
             "traffic_source": src if dom_counter is not None else
             "none committed for these kernel sources and this workload: design bytes",
             "avg_launch_ms": ksum[dom],
