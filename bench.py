@@ -637,7 +637,7 @@ def main():
     # ---- overlap-resolving decode: the reference's own Viterbi-test model,
     # test/runtests.jl:17-34 -- 2 templates, K=60, allow_overlaps=true, 3600 states -- through the
     # blocked engine, device-resident (untimed extra, rank 0 of a 1-GPU run only) ----
-    def overlap_decode(To=2_000_000):
+    def overlap_decode(To=10_000_000):
         Ko = 60
         t2 = np.asfortranarray(np.stack([H.create_spike_template(Ko, 3.0, 0.8, 0.2),
                                          H.create_spike_template(Ko, 4.0, 0.3, 0.2)], 1))
@@ -656,7 +656,7 @@ def main():
         d = po.diagnostics(stream)
         po.close()
         return {"model": "N=2 K=%d allow_overlaps=true, %d states" % (Ko, smo.nstates), "samples": To,
-                "engine": {1: "strict", 2: "ring", 3: "blocked"}.get(io["engine"], io["engine"]),
+                "engine": {1: "strict", 2: "ring", 3: "blocked (pair sweep: pair runs as delays, lanes = phases)"}.get(io["engine"], io["engine"]),
                 "block": io["block"], "halo": io["halo"], "Msamples_s": To / per / 1e6,
                 "boundary_check_fails": d[0], "max_boundary_spread": d[2], "near_tie_blocks": d[7]}
     ov = overlap_decode() if (rank == 0 and world == 1 and not args.quick) else None

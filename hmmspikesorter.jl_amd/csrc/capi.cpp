@@ -722,6 +722,13 @@ static int viterbi_host(const void *y, int sample_type, int64_t T, const int16_t
             }
         }
         last_escalations() = attempt + 1;
+        if (ties && diag[0] == 0 && h.plan->gen && generic_pair_active(h.plan->gen)) {
+            // two-template overlap model: a decision on the path is inside the noise of the pair sweep's own
+            // arithmetic -- decode again with the generic blocked sweep (the reference's operation order per block)
+            generic_pair_disable(h.plan->gen);
+            keep = false;
+            continue;
+        }
         halo = next_halo(h.plan);
         if (attempt >= 3 || halo > T || ties) {
             // near-ties depend on the frame, not on the warm-up: straight to the op-for-op sweep

@@ -549,7 +549,7 @@ __global__ void k_block_ties(const double *__restrict__ frame, const unsigned lo
 __device__ __forceinline__ int back_step(const int32_t *bt, const int16_t *row, int v)
 {
     const int code = bt[v - 1];
-    return code > 0 ? code : (int)row[-code];
+    return code > 0 ? code : ((int)row[-code] & 0x7fff);   // bit 15: near-tie flag of the pair sweep (pair_sweep.hip)
 }
 
 // All S end states of block c walked back to its first sample, rows of T2c staged through LDS W at
@@ -852,6 +852,21 @@ int blocked_set_model(GenericDev *g, const HostModel &m)
         HS_HIP(hipMemcpy(g->d_tsrc, tsrc.data(), tsrc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         HS_HIP(hipMemcpy(g->d_tlp, tlp.data(), tlp.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    // two-template overlap models: the sweep that treats pair runs as delays (pair_sweep.hip); its back-pointer
+    // rows are the multi-source states silent, A_k, B_k in state order
+    g->pair_ok = false;
+    if (!g->pair_off && !(getenv("HMMSORT_PAIR") && atoi(getenv("HMMSORT_PAIR")) == 0)) {
+        std::vector<double> tab;
+        const int64_t L = m.K - 1;
+        bool ok = pair_analyze(m, tab) && (int64_t)ms.size() == 2 * L + 1;
+        for (size_t q = 0; ok && q < ms.size(); q++) ok = ms[q].j == (int32_t)q;
+        if (ok) {
+            int rc;
+            if (!g->d_pairtab && (rc = dalloc(&g->d_pairtab, tab.size(), &g->bytes))) return rc;
+            HS_HIP(hipMemcpy(g->d_pairtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+            g->pair_ok = true;
+        }
+    }
     return HMMSORT_OK;
 }
 
@@ -876,7 +891,7 @@ int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t
         (rc = dalloc(&g->d_fmap, nb * S, &g->bytes)) || (rc = dalloc(&g->d_merged, nb, &g->bytes)) ||
         (rc = dalloc(&g->d_endstate, nb, &g->bytes)) || (rc = dalloc(&g->d_fconst, nb, &g->bytes)) || (rc = dalloc(&g->d_llpart, 3 * nb, &g->bytes)) ||
         (rc = dalloc(&g->d_bdiag, 8, &g->bytes)) || (rc = dalloc(&g->d_gapmin, nb, &g->bytes)) ||
-        (rc = dalloc(&g->d_frame, 2 * nb, &g->bytes)))
+        (rc = dalloc(&g->d_frame, 2 * nb, &g->bytes)) || (rc = dalloc(&g->d_qsum, nb + 64, &g->bytes)))   // [0] sum y^2 of the pair sweep, [8..] its trash line
         return rc;
     HS_HIP(hipMemset(g->d_frame, 0, 2 * nb * sizeof(double)));
     if (!g->blk_cols_lds && !g->blk_onecol && (rc = dalloc(&g->d_blkbuf, nb * 2 * S, &g->bytes)))
@@ -888,7 +903,7 @@ int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t
 void blocked_destroy(GenericDev *g)
 {
     void *ptrs[] = {g->d_lp0, g->d_src0, g->d_tinfo, g->d_tsrc, g->d_tlp, g->d_endv, g->d_warmv,
-                    g->d_fmap, g->d_merged, g->d_endstate, g->d_llpart, g->d_bdiag, g->d_blkbuf, g->d_ms, g->d_bt, g->d_fconst, g->d_lpdict, g->d_lpidx, g->d_gapmin, g->d_frame};
+                    g->d_fmap, g->d_merged, g->d_endstate, g->d_llpart, g->d_bdiag, g->d_blkbuf, g->d_ms, g->d_bt, g->d_fconst, g->d_lpdict, g->d_lpidx, g->d_gapmin, g->d_frame, g->d_pairtab, g->d_qsum};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -942,7 +957,9 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     HS_HIP(hipMemsetAsync(g->d_gapmin, 0x7f, (size_t)g->nblk * sizeof(unsigned long long), st));  // huge
     int rc;
     const bool gcol = !g->blk_cols_lds, tl = g->blk_tail_lds;
-    if (g->blk_onecol) {
+    if (g->pair_ok) {
+        rc = pair_sweep_launch(g, d_y, st);
+    } else if (g->blk_onecol) {
         const size_t lds1 = (size_t)(S + 1) * 8 + (size_t)g->ntail * 12 + 8;
         const int spt1 = (int)((S + 1023) / 1024);
         auto go = [&](auto kern) -> int {
@@ -988,8 +1005,10 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
                            g->d_bdiag, g->d_frame);
         HS_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_block_ties, dim3(1), dim3(64), 0, st, g->d_frame, g->d_gapmin, nb, g->d_bdiag);
-    HS_HIP(hipGetLastError());
+    if (!g->pair_ok) {
+        hipLaunchKernelGGL(k_block_ties, dim3(1), dim3(64), 0, st, g->d_frame, g->d_gapmin, nb, g->d_bdiag);
+        HS_HIP(hipGetLastError());
+    }
     // backtrace: rows of T2c staged W at a time; bt in LDS when it fits
     const int nms1 = std::max(g->nms, 1);
     int W = (int)std::max<int64_t>(1, std::min<int64_t>(64, (32 * 1024) / (nms1 * 2)));
@@ -1008,6 +1027,7 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     hipLaunchKernelGGL(k_block_finish, dim3((nb + 63) / 64), dim3(64), 0, st, g->d_T2, g->d_bt, g->nms,
                        T, (int)S, (int)g->B, nb, g->d_endstate, g->d_merged, d_x);
     HS_HIP(hipGetLastError());
+    if (g->pair_ok && (rc = pair_ties_launch(g, d_x, st))) return rc;   // flagged decisions ON the decoded path -> diag[7]
     hipLaunchKernelGGL(k_block_ll, dim3(nb), dim3(256), 0, st, d_y, d_x, T, (int)S, (int)g->B,
                        g->d_mean, g->d_in_ptr, g->d_in_src, g->d_in_lp, a.c0, a.den, g->d_llpart);
     HS_HIP(hipGetLastError());
@@ -1016,6 +1036,9 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     HS_HIP(hipGetLastError());
     return HMMSORT_OK;
 }
+
+bool generic_pair_active(const GenericDev *g) { return g && g->blocked && g->pair_ok; }
+void generic_pair_disable(GenericDev *g) { g->pair_off = true; g->pair_ok = false; }
 
 int blocked_diagnostics(GenericDev *g, hipStream_t st, int64_t diag[8])
 {

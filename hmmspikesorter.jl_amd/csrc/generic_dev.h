@@ -40,6 +40,9 @@ struct GenericDev {
     int64_t *d_merged = nullptr;
     unsigned long long *d_bdiag = nullptr, *d_gapmin = nullptr;
     double *d_frame = nullptr;  // per block: frame constant relative to the previous block, |values|
+    // structure-exploiting sweep for two-template overlap models (pair_sweep.hip)
+    bool pair_ok = false, pair_off = false;   // pair_off: the host fell back to the generic sweep for this plan
+    double *d_pairtab = nullptr, *d_qsum = nullptr;
     // time-parallel E-step (generic_estep.hip), allocated on first use
     double *d_es_win = nullptr, *d_es_rec = nullptr, *d_es_partG = nullptr, *d_es_partX = nullptr;
     double *d_es_inw = nullptr, *d_es_outw = nullptr, *d_es_tmp = nullptr;
@@ -51,6 +54,10 @@ struct GenericDev {
 };
 
 int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t halo_req);
+// pair_sweep.hip
+bool pair_analyze(const HostModel &m, std::vector<double> &tab);
+int pair_sweep_launch(GenericDev *g, const double *d_y, hipStream_t st);
+int pair_ties_launch(GenericDev *g, const int16_t *d_x, hipStream_t st);
 int blocked_set_model(GenericDev *g, const HostModel &m);
 void blocked_destroy(GenericDev *g);
 int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st);

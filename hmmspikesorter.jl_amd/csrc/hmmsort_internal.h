@@ -91,6 +91,10 @@ struct RingDev;     // ring_engine.hip
 int generic_create(GenericDev **g, const HostModel &m, int64_t T, bool blocked = false,
                    int64_t block_req = 0, int64_t halo_req = 0);
 bool generic_is_blocked(const GenericDev *g);
+// two-template overlap models: the blocked engine's structure-exploiting sweep (pair_sweep.hip) is in use /
+// switch it off for this plan (host fallback to the generic blocked sweep when a near-tie is flagged on the path)
+bool generic_pair_active(const GenericDev *g);
+void generic_pair_disable(GenericDev *g);
 void generic_geometry(const GenericDev *g, int64_t *block, int64_t *halo, int64_t *nblocks);
 int generic_diagnostics(GenericDev *g, hipStream_t st, int64_t diag[8]);
 int64_t blocked_min_samples();

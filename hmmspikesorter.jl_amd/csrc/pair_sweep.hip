@@ -1,0 +1,387 @@
+// Blocked engine, structure-exploiting sweep for overlap models of TWO templates (reference
+// types.jl:65-127 with allow_overlaps = true, N = 2: the model of the reference's own Viterbi test,
+// test/runtests.jl:17-34, 3600 states at K = 60).
+//
+// isvalid_transition (types.jl:94-113) makes the overlap model a PRODUCT of per-neuron chains: silent
+// (lpz per step), start (lp_i), a ring of L = K-1 deterministic steps, restricted to states that exist.  With
+// A_k / B_k = "only neuron 1 / 2 active, phase k" and P(k1,k2) = both active:
+//   * a pair state has exactly one predecessor: P(k1,k2) <- P(k1-1,k2-1), P(k+1,1) <- A_k, P(1,k+1) <- B_k,
+//     P(1,1) <- silent, all inside the pair lattice with log-probability 0.  A pair run is therefore a pure
+//     DELAY: what enters at P(k+1,1) leaves at P(L,L-k) after L-k-1 steps, having collected the emissions on
+//     its diagonal -- and those separate: with means as deviations a, b from the silent mean,
+//         (y-m0-a-b)^2 = (y-m0-a)^2 + (y-m0-b)^2 - (y-m0)^2 + 2ab,
+//     so in gains g = q - q_silent a pair state's gain is gA + gB - 2ab/den, the last term a table;
+//   * only the 2L+1 states silent, A_k, B_k take decisions: A_k <- {A_(k-1), P(k-1,L)} ("continue alone" or
+//     "the partner just ended"), A_1 <- {silent, B_L}, silent <- {silent, A_L, B_L, P(L,L)}.
+// A wavefront whose LANES ARE PHASES advances one sample per step: the single tracks dA, dB and the prefix
+// gains sA[k](t) = sum_{j<=k} gA_j(t-k+j) shift by one lane (DPP), the pair entry that exits into lane k is read
+// from a skewed L x L buffer in LDS (written by lane L-k+1 of the other track k-1 steps earlier), and a pair
+// run's total gain is sA[L] - sA[k] + sB[L-k] - CC(k) with CC the table of summed 2ab/den along the diagonal.
+// ~90 instructions per sample instead of 3600 x 13.
+//
+// Everything around the sweep is the blocked engine's (generic_blocked.hip): blocks with a warm-up from a flat
+// column, full trellis columns at the block boundaries for the certificate (pair states are materialised from
+// their entries there), back-pointers of the multi-source states in T2c, exact backtrace, ll.  The arithmetic
+// differs from the reference's operation order (gains, prefix sums) by ~1e-12, so every decision whose margin is
+// below thr = 16 (L+2) ulp(|T1|max) + 1e-10 -- the worst case of the reference's own rounding for paths apart for up
+// to 8 (L+2) steps (wave_viterbi.hip) plus this sweep's noise -- carries a flag in bit 15 of its back-pointer, and
+// the flagged decisions ON THE DECODED PATH are counted in diag[7]; hmmsort_viterbi then decodes with the generic
+// blocked sweep (the reference's operation order) and, should that flag too, with the strict engine.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include "generic_dev.h"
+#include "hmmsort_internal.h"
+#include "wave_common.h"   // DPP lane moves
+
+namespace hmmsort {
+
+constexpr int kPairTab = 16 + 4 * 64 + 2 * 64 * 64 + 64;   // doubles in the device table (layout below)
+// table layout: [0..15] c00 c0A c0B c0P cAA cAP cA0 cAB cBB cBP cB0 cBA m0 CC0 - -
+//   [16..79] a[k] (k = 1..L at index k-1), [80..143] b, [144..207] CCab[d], [208..271] CCba[d]  (d = 1..L-1)
+//   [272 .. 272+4095] CCpartAB[d*64+n], then CCpartBA[d*64+n], then CCpart0[n]
+constexpr int kPT_A = 16, kPT_B = 80, kPT_CCAB = 144, kPT_CCBA = 208, kPT_PAB = 272, kPT_PBA = 272 + 4096,
+              kPT_P0 = 272 + 8192;
+
+struct PairArgs {
+    const double *y;
+    int64_t T;
+    int S, B, H, L, nms;
+    const double *tab;
+    double c0, den;
+    int16_t *T2c;
+    double *endv, *warmv;
+    double *qsum;          // [0]: sum over the recording of (y - m0)^2, for the near-tie threshold
+    int16_t *trash;        // 192 entries: where warm-up steps and idle lanes store
+};
+
+// Host: is this transition list the two-template overlap pattern, with the values the sweep assumes?
+bool pair_analyze(const HostModel &m, std::vector<double> &tab)
+{
+    if (m.N != 2 || m.K < 3) return false;
+    const int L = (int)m.K - 1;
+    if (L > 63 || m.S != 1 + 2 * (int64_t)L + (int64_t)L * L || m.R != (int64_t)(L + 2) * (L + 2)) return false;
+    // state table of generate_states(2, K, true) (1-based rows of mu)
+    auto st = [&](int neuron, int64_t j) { return (int)m.states[neuron + 2 * j] - 1; };
+    if (st(0, 0) != 0 || st(1, 0) != 0) return false;
+    for (int k = 1; k <= L; k++) {
+        if (st(0, k) != k || st(1, k) != 0 || st(0, L + k) != 0 || st(1, L + k) != k) return false;
+        for (int k2 = 1; k2 <= L; k2++) {
+            const int64_t j = 2 * L + (int64_t)(k - 1) * L + k2;
+            if (st(0, j) != k || st(1, j) != k2) return false;
+        }
+    }
+    std::map<std::pair<int64_t, int64_t>, double> lp;
+    for (const auto &t : m.tr) lp[{t.src - 1, t.dst - 1}] = t.lp;
+    if ((int64_t)lp.size() != m.R) return false;
+    auto A = [&](int k) { return (int64_t)k; };
+    auto Bs = [&](int k) { return (int64_t)L + k; };
+    auto P = [&](int k1, int k2) { return (int64_t)2 * L + (int64_t)(k1 - 1) * L + k2; };
+    bool ok = true;
+    auto get = [&](int64_t s, int64_t d) {
+        auto it = lp.find({s, d});
+        if (it == lp.end() || !std::isfinite(it->second)) { ok = false; return 0.0; }
+        return it->second;
+    };
+    auto same = [&](double v, double ref) { if (!(v == ref)) ok = false; };
+    const double c00 = get(0, 0), c0A = get(0, A(1)), c0B = get(0, Bs(1)), c0P = get(0, P(1, 1));
+    const double cAA = L > 1 ? get(A(1), A(2)) : 0.0, cAP = L > 1 ? get(A(1), P(2, 1)) : 0.0;
+    const double cBB = L > 1 ? get(Bs(1), Bs(2)) : 0.0, cBP = L > 1 ? get(Bs(1), P(1, 2)) : 0.0;
+    const double cA0 = get(A(L), 0), cAB = get(A(L), Bs(1)), cB0 = get(Bs(L), 0), cBA = get(Bs(L), A(1));
+    for (int k = 1; k < L && ok; k++) {
+        same(get(A(k), A(k + 1)), cAA); same(get(A(k), P(k + 1, 1)), cAP);
+        same(get(Bs(k), Bs(k + 1)), cBB); same(get(Bs(k), P(1, k + 1)), cBP);
+        same(get(P(L, k), Bs(k + 1)), 0.0); same(get(P(k, L), A(k + 1)), 0.0);   // the partner ends: log-probability 0
+        for (int k2 = 1; k2 < L && ok; k2++) same(get(P(k, k2), P(k + 1, k2 + 1)), 0.0);
+    }
+    if (ok) same(get(P(L, L), 0), 0.0);
+    if (!ok) return false;
+    // means: pair state = silent mean + both deviations (up to the rounding of the neuron-order sums)
+    const double m0 = m.mean[0], den = 2.0 * (m.sigma * m.sigma);
+    std::vector<double> a(L + 1, 0.0), b(L + 1, 0.0);
+    double scale = std::fabs(m0) + 1e-300;
+    for (int k = 1; k <= L; k++) {
+        a[k] = m.mean[A(k)] - m0; b[k] = m.mean[Bs(k)] - m0;
+        scale = std::max(scale, std::max(std::fabs(a[k]), std::fabs(b[k])));
+    }
+    for (int k1 = 1; k1 <= L; k1++)
+        for (int k2 = 1; k2 <= L; k2++)
+            if (std::fabs(m.mean[P(k1, k2)] - (m0 + a[k1] + b[k2])) > 1e-12 * scale) return false;
+    tab.assign(kPairTab, 0.0);
+    const double cs[14] = {c00, c0A, c0B, c0P, cAA, cAP, cA0, cAB, cBB, cBP, cB0, cBA, m0, 0.0};
+    for (int i = 0; i < 14; i++) tab[i] = cs[i];
+    auto cc = [&](int k1, int k2) { return 2.0 * a[k1] * b[k2] / den; };
+    for (int k = 1; k <= L; k++) { tab[kPT_A + k - 1] = a[k]; tab[kPT_B + k - 1] = b[k]; }
+    // A ahead by d (entered from A_d into P(d+1,1)): terms cc(d+1+i, 1+i), i = 0..L-d-1; CCpart(d,n) = first n terms
+    for (int d = 0; d <= L - 1; d++) {
+        double sab = 0.0, sba = 0.0;
+        for (int n = 0; n <= L - d; n++) {
+            if (d >= 1) { tab[kPT_PAB + d * 64 + n] = sab; tab[kPT_PBA + d * 64 + n] = sba; }
+            else tab[kPT_P0 + n] = sab;
+            if (n < L - d) { sab += cc(d + 1 + n, 1 + n); sba += cc(1 + n, d + 1 + n); }
+        }
+        if (d >= 1) { tab[kPT_CCAB + d] = sab; tab[kPT_CCBA + d] = sba; }
+        else tab[13] = sab;
+    }
+    return true;
+}
+
+__device__ __forceinline__ double pair_bcast(double v, int lane) { return wave_bcast(v, lane); }
+
+// Skewed entry buffer: an entry of column d (written by lane d of the track that is ahead by d phases) is read
+// L - d steps later, so column d is a FIFO of pairfifo(L, d) = the power of two above L - d slots, addressed by
+// time & (len - 1).  Columns are packed one after the other: 2474 slots per direction at L = 59 instead of a
+// 64 x 64 square -- 39 KB of LDS per wavefront, i.e. four wavefronts per CU instead of two.
+__host__ __device__ inline int pairfifo(int L, int d)
+{
+    int n = 2;
+    while (n < L - d + 1) n <<= 1;
+    return n;
+}
+__host__ __device__ inline int pairbase(int L, int d)   // slots of the columns before d (column 0: silent -> P(1,1))
+{
+    int b = 0;
+    for (int q = 0; q < d; q++) b += pairfifo(L, q);
+    return b;
+}
+
+__global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
+{
+    extern __shared__ double eb[];            // EAB columns 0..L-1 | EBA columns 1..L-1 | 64 samples | column bases
+    const int nAB = pairbase(a.L, a.L), nBA = nAB - pairfifo(a.L, 0), msk0 = pairfifo(a.L, 0) - 1;
+    double *EAB = eb, *EBA = eb + nAB - pairfifo(a.L, 0);          // EBA[pairbase(d)] is valid for d >= 1
+    double *YB = eb + nAB + nBA;
+    int *CB = reinterpret_cast<int *>(YB + 64);                    // CB[d] = base of column d, CB[64 + d] = its mask
+    const int lane = threadIdx.x, c = blockIdx.x, L = a.L, S = a.S;
+    const int k = lane + 1;                   // this lane's phase
+    const bool on = lane < L;
+    const int64_t s = (int64_t)c * a.B;
+    const int64_t e = (s + a.B < a.T) ? s + a.B : a.T;
+    const int64_t w = (s - a.H > 0) ? s - a.H : 0;
+    const double *tab = a.tab;
+    const double c00 = tab[0], c0A = tab[1], c0B = tab[2], c0P = tab[3], cAA = tab[4], cAP = tab[5], cA0 = tab[6],
+                 cAB = tab[7], cBB = tab[8], cBP = tab[9], cB0 = tab[10], cBA = tab[11], m0 = tab[12], CC0 = tab[13];
+    const double rden = 1.0 / a.den;
+    // near-tie threshold: magnitude the reference's trellis reaches on this recording (as wave_thr)
+    const double mmax = fabs(a.c0) * (double)a.T + a.qsum[0] * rden + fabs(c00) * (double)a.T + 1.0;
+    const double thr = ldexp(16.0 * (double)(L + 2), ilogb(mmax) - 52) + 1e-10;
+    const double ak = on ? tab[kPT_A + lane] : 0.0, bk = on ? tab[kPT_B + lane] : 0.0;
+    const double akr = ak * rden, bkr = bk * rden;
+    // the pair run that exits into this lane entered with d = L - lane (lanes 1..L-1)
+    const int dex = L - lane;
+    const bool has_exit = on && lane >= 1;
+    const double CCab_r = has_exit ? tab[kPT_CCAB + dex] : 0.0, CCba_r = has_exit ? tab[kPT_CCBA + dex] : 0.0;
+    // state ids (1-based, as the back-pointers store them)
+    const int idA = 1 + k, idB = 1 + L + k;
+    const int idPA = 1 + 2 * L + (k - 2) * L + L;          // P(k-1, L) -> A_k
+    const int idPB = 1 + 2 * L + (L - 1) * L + (k - 1);    // P(L, k-1) -> B_k
+    const int idAL = 1 + L, idBL = 1 + 2 * L, idPLL = 1 + 2 * L + L * L;
+
+    for (int i = lane; i < nAB + nBA; i += 64) eb[i] = 0.0;
+    if (lane < L) { CB[lane] = pairbase(L, lane); CB[64 + lane] = pairfifo(L, lane) - 1; }
+    __syncthreads();
+    // this lane's columns: it WRITES column k (entries of the pair runs it starts), it READS column L - lane
+    const int wcol = (on && k <= L - 1) ? CB[k] : 0, wmsk = (on && k <= L - 1) ? CB[64 + k] : 0;
+    const int rcol = has_exit ? CB[dex] : 0, rmsk = has_exit ? CB[64 + dex] : 0;
+    // virtual entries: every pair state is present in the first column with its emission (viterbi.jl:55-63; the
+    // flat start of a warm-up alike).  The pair (d + n + 1, n + 1) "entered" n samples before w; its entry holds
+    // the part of CC that lies before w, so that exits and materialised columns come out right.
+    {
+        const int d = lane;
+        for (int n = 0; n < L; n++) {
+            if (d == 0) EAB[(int)((w - n) & msk0)] = tab[kPT_P0 + n];
+            else if (d <= L - 1 - n) {
+                const int pos = CB[d] + (int)((w - n) & CB[64 + d]);
+                EAB[pos] = tab[kPT_PAB + d * 64 + n];
+                EBA[pos] = tab[kPT_PBA + d * 64 + n];
+            }
+        }
+    }
+    __syncthreads();
+    double D0, dA, dB, sA, sB;
+    {
+        const double u = a.y[w] - m0;
+        const double gA = on ? ((2.0 * u - ak) * akr) : 0.0, gB = on ? ((2.0 * u - bk) * bkr) : 0.0;
+        dA = gA; dB = gB; sA = gA; sB = gB;
+        const double q0 = a.c0 - (u * u) * rden;
+        D0 = (w == 0) ? -q0 : 0.0;            // T1[1,1] = 0 (viterbi.jl:63) in the frame that drops c0 + q0 per sample
+    }
+    // full trellis column (frame of this block) at the current sample: singles from the registers, pair states from
+    // their entries
+    auto dump = [&](double *col, int64_t t) {
+        if (lane == 0) col[0] = D0;
+        if (on) { col[k] = dA; col[L + k] = dB; }
+        for (int k2 = 1; k2 <= L; k2++) {
+            const double sBk2 = pair_bcast(sB, k2 - 1);
+            if (on) {
+                const int d = k - k2;
+                double v;
+                if (d > 0) v = EAB[CB[d] + (int)((t - k2 + 1) & CB[64 + d])] - tab[kPT_PAB + d * 64 + k2];
+                else if (d == 0) v = EAB[(int)((t - k2 + 1) & msk0)] - tab[kPT_P0 + k2];
+                else v = EBA[CB[-d] + (int)((t - k + 1) & CB[64 - d])] - tab[kPT_PBA + (-d) * 64 + k];
+                col[2 * L + (k - 1) * L + k2] = (v + sA) + sBk2;
+            }
+        }
+    };
+    // samples reach the wavefront 64 at a time through LDS (the next 64 are in flight meanwhile) and a step reads its
+    // sample as an LDS broadcast: a register filled by a global load would make every step wait on vmcnt, i.e. for
+    // the previous step's back-pointer stores to reach L2 (measured: 0.55 us per step instead of ~0.15)
+    auto ychunk = [&](int64_t tc) { const int64_t ti = tc + lane; return a.y[ti < e ? ti : e - 1]; };
+    double ynxt = ychunk(w + 1);
+    for (int64_t tc = w + 1; tc < e; tc += 64) {
+      YB[lane] = ynxt;
+      ynxt = ychunk(tc + 64 < e ? tc + 64 : tc);
+      const int nstep = (e - tc) < 64 ? (int)(e - tc) : 64;
+      for (int si = 0; si < nstep; si++) {
+        const int64_t t = tc + si;
+        const double yt = YB[si];
+        const bool own = t >= s;
+        if (t == s && s > 0) {                 // the column of sample s-1 is what the boundary certificate compares
+            __syncthreads();
+            dump(a.warmv + (int64_t)c * S, t - 1);
+        }
+        const double u = yt - m0;
+        const double gA = on ? ((2.0 * u - ak) * akr) : 0.0, gB = on ? ((2.0 * u - bk) * bkr) : 0.0;
+        // values of the previous sample: own lane, lane k-1, lane L
+        const double pdA = lane_prev(dA, 0.0), pdB = lane_prev(dB, 0.0);
+        const double psA = lane_prev(sA, 0.0), psB = lane_prev(sB, 0.0);
+        const double dAL = pair_bcast(dA, L - 1), dBL = pair_bcast(dB, L - 1);
+        const double sAL = pair_bcast(sA, L - 1), sBL = pair_bcast(sB, L - 1);
+        // pair runs that end now (entered lane steps ago by lane L-k+1 of the other track)
+        const int rpos = rcol + (((int)t - lane) & rmsk);          // (lanes without an exit read slot 0 of column 0: unused)
+        const double xa = ((EBA[has_exit ? rpos : CB[1]] + sBL) + psA) - CCba_r;      // P(k-1, L) at t-1
+        const double xb = ((EAB[rpos] + sAL) + psB) - CCab_r;      // P(L, k-1) at t-1
+        const double xp = ((EAB[(int)((t - L) & msk0)] + sAL) + sBL) - CC0;   // P(L, L) at t-1 (wave-uniform)
+        // entries of this sample (from the previous sample's singles)
+        if (on && k <= L - 1) {
+            const int wpos = wcol + ((int)t & wmsk);
+            EAB[wpos] = (dA + cAP) - sA; EBA[wpos] = (dB + cBP) - sB;
+        }
+        if (lane == 0) EAB[(int)(t & msk0)] = D0 + c0P;
+        // decisions, list order = source index ascending, strict '>' (viterbi.jl:74-84)
+        double c1a, c2a, c1b, c2b;
+        if (lane == 0) { c1a = D0 + c0A; c2a = dBL + cBA; c1b = D0 + c0B; c2b = dAL + cAB; }
+        else { c1a = pdA + cAA; c2a = xa; c1b = pdB + cBB; c2b = xb; }
+        // B_1 <- {silent, A_L}: A_L (index 1+L) comes after silent; A_1 <- {silent, B_L} likewise
+        const bool wa = c2a > c1a, wb = c2b > c1b;
+        const double nA = (wa ? c2a : c1a) + gA, nB = (wb ? c2b : c1b) + gB;
+        const int argA = lane == 0 ? (wa ? idBL : 1) : (wa ? idPA : idA - 1);
+        const int argB = lane == 0 ? (wb ? idAL : 1) : (wb ? idPB : idB - 1);
+        double best = D0 + c00, sec = -INFINITY;   // margin of the winner over the runner-up (losers may tie freely)
+        int arg0 = 1;
+        {
+            const double t1 = dAL + cA0, t2 = dBL + cB0;
+            if (t1 > best) { sec = best; best = t1; arg0 = idAL; } else sec = fmax(sec, t1);
+            if (t2 > best) { sec = best; best = t2; arg0 = idBL; } else sec = fmax(sec, t2);
+            if (xp > best) { sec = best; best = xp; arg0 = idPLL; } else sec = fmax(sec, xp);
+        }
+        const double g0 = best - sec;
+        {   // straight-line stores (warm-up steps and idle lanes write a trash line): stores under divergent
+            // branches make hipcc wait for vmcnt(0) every step, i.e. for the previous step's stores to reach L2
+            int16_t *psi = a.T2c + (int64_t)a.nms * t;
+            const bool st = own && on;
+            *(st ? psi + k : a.trash + lane) = (int16_t)(argA | (fabs(c2a - c1a) < thr ? 0x8000 : 0));
+            *(st ? psi + L + k : a.trash + 64 + lane) = (int16_t)(argB | (fabs(c2b - c1b) < thr ? 0x8000 : 0));
+            *((own && lane == 0) ? psi : a.trash + 128 + lane) = (int16_t)(arg0 | (g0 < thr ? 0x8000 : 0));
+        }
+        D0 = best;
+        dA = on ? nA : 0.0; dB = on ? nB : 0.0;
+        sA = on ? psA + gA : 0.0; sB = on ? psB + gB : 0.0;
+        if (lane == 0) { sA = gA; sB = gB; }
+        // (LDS operations of one wavefront execute in order: the next sample's reads see this sample's entries)
+      }
+    }
+    __syncthreads();
+    dump(a.endv + (int64_t)c * S, e - 1);
+}
+
+// sum over the recording of (y - m0)^2 (one double; the magnitude of the reference's trellis)
+__global__ __launch_bounds__(256) void k_pair_mag(const double *__restrict__ y, int64_t T, const double *__restrict__ tab,
+                                                  double *__restrict__ out)
+{
+    __shared__ double red[4];
+    const double m0 = tab[12];
+    double acc = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (int64_t)gridDim.x * blockDim.x) {
+        const double u = y[t] - m0;
+        acc = __builtin_fma(u, u, acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// flagged decisions on the decoded path: the state at sample t is a deciding state (silent, A_k, B_k) whose
+// back-pointer of that sample carries the flag.  (The final arg-max over the end states is the blocked engine's,
+// on columns materialised to ~1e-12: its margin is checked by k_pair_tail.)
+__global__ __launch_bounds__(256) void k_pair_ties(const int16_t *__restrict__ x, const int16_t *__restrict__ T2c,
+                                                   int64_t T, int nms, unsigned long long *diag)
+{
+    unsigned long long n = 0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; t < T; t += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)x[t] - 1;
+        if (j < nms && (T2c[t * nms + j] & (int16_t)0x8000)) n++;
+    }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&diag[7], n);
+}
+
+// margin of the final arg-max (viterbi.jl:90) over the last block's end column
+__global__ __launch_bounds__(256) void k_pair_tail(const double *__restrict__ endv_last, int S, const double *__restrict__ qsum,
+                                                   const double *__restrict__ tab, double c0, double den, int64_t T, int L,
+                                                   unsigned long long *diag)
+{
+    __shared__ double b1[256], b2[256];
+    double best = -INFINITY, sec = -INFINITY;
+    for (int j = threadIdx.x; j < S; j += 256) {
+        const double v = endv_last[j];
+        if (v > best) { sec = best; best = v; } else sec = fmax(sec, v);
+    }
+    b1[threadIdx.x] = best; b2[threadIdx.x] = sec;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = -INFINITY; sec = -INFINITY;
+        for (int i = 0; i < 256; i++) {
+            if (b1[i] > best) { sec = fmax(sec, best); best = b1[i]; } else sec = fmax(sec, b1[i]);
+            sec = fmax(sec, b2[i]);
+        }
+        const double mmax = fabs(c0) * (double)T + qsum[0] / den + fabs(tab[0]) * (double)T + 1.0;
+        const double thr = ldexp(16.0 * (double)(L + 2), ilogb(mmax) - 52) + 1e-10;
+        if (best - sec < thr) atomicAdd(&diag[7], 1ull);
+    }
+}
+
+int pair_sweep_launch(GenericDev *g, const double *d_y, hipStream_t st)
+{
+    PairArgs a;
+    a.y = d_y; a.T = g->T; a.S = (int)g->S; a.B = (int)g->B; a.H = (int)g->H; a.L = (int)g->K - 1; a.nms = g->nms;
+    a.tab = g->d_pairtab;
+    a.c0 = -kLog2Pi - g->lsig;
+    a.den = 2.0 * (g->sigma * g->sigma);
+    a.T2c = g->d_T2; a.endv = g->d_endv; a.warmv = g->d_warmv; a.qsum = g->d_qsum;
+    a.trash = reinterpret_cast<int16_t *>(g->d_qsum + 8);   // d_qsum has nblk >= ... doubles; see blocked_create
+    HS_HIP(hipMemsetAsync(g->d_qsum, 0, sizeof(double), st));
+    hipLaunchKernelGGL(k_pair_mag, dim3((unsigned)std::min<int64_t>(1024, (g->T + 255) / 256)), dim3(256), 0, st, d_y, g->T,
+                       g->d_pairtab, g->d_qsum);
+    const int L_ = (int)g->K - 1;
+    const size_t lds = (size_t)(2 * pairbase(L_, L_) - pairfifo(L_, 0) + 64) * sizeof(double) + 128 * sizeof(int);
+    HS_HIP(hipFuncSetAttribute((const void *)pair_vit_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(pair_vit_block, dim3((unsigned)g->nblk), dim3(64), lds, st, a);
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+int pair_ties_launch(GenericDev *g, const int16_t *d_x, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pair_ties, dim3((unsigned)std::min<int64_t>(2048, (g->T + 255) / 256)), dim3(256), 0, st, d_x,
+                       g->d_T2, g->T, g->nms, g->d_bdiag);
+    hipLaunchKernelGGL(k_pair_tail, dim3(1), dim3(256), 0, st, g->d_endv + (g->nblk - 1) * g->S, (int)g->S, g->d_qsum,
+                       g->d_pairtab, -kLog2Pi - g->lsig, 2.0 * (g->sigma * g->sigma), g->T, (int)g->K - 1, g->d_bdiag);
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
+}
+
+}  // namespace hmmsort

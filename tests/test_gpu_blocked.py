@@ -210,3 +210,77 @@ def test_duplicate_templates_near_ties_are_detected(O, H):
         x, ll = H.viterbi(y, sm, temps, 0.28)
         xo, llo = O.viterbi(y, to_oracle_sm(O, sm), temps, 0.28)
         assert np.array_equal(x, xo) and abs(ll - llo) <= LL_RTOL * abs(llo)
+
+
+# ---- two-template overlap models: the sweep that treats pair runs as delays (csrc/pair_sweep.hip) ----------
+
+def _pair_case(H, K, T, seed, silent_mean=(0.0, 0.0), amp=(3.0, 4.0)):
+    t1 = H.create_spike_template(K, amp[0], 0.8, 0.2)
+    t2 = H.create_spike_template(K, amp[1], 0.3, 0.2)
+    temps = np.asfortranarray(np.stack([t1, t2], 1))
+    pp = [0.003, 0.0015]
+    y = H.create_signal(T, 0.3, pp, temps, seed=seed)
+    rng = np.random.default_rng(seed)
+    L = K - 1
+    for _ in range(max(4, T // 4000)):                      # overlapping pairs at random offsets, both orders
+        t0 = int(rng.integers(L, T - 3 * L))
+        d = int(rng.integers(0, L))
+        a, b = (0, 1) if rng.random() < 0.5 else (1, 0)
+        y[t0:t0 + L] += temps[1:, a]
+        y[t0 + d:t0 + d + L] += temps[1:, b]
+    mu = temps.copy(order="F")
+    mu[0, :] = silent_mean
+    sm = H.StateMatrix.create(2, K, np.log(pp), True)
+    return y, sm, mu
+
+
+@pytest.mark.parametrize("K,T,seed,silent_mean,sigma", [
+    (60, 60_000, 1, (0.0, 0.0), 0.3),
+    (60, 300_000, 2, (0.02, -0.01), 0.35),       # nonzero silent means: deviations from the silent state's mean
+    (64, 40_000, 3, (0.0, 0.0), 0.25),           # longest ring the sweep takes (63 phases)
+    (20, 30_000, 4, (0.0, 0.0), 0.3),
+    (5, 8_000, 5, (0.0, 0.0), 0.3),
+    (3, 5_000, 6, (0.0, 0.0), 0.3),              # two phases per ring
+    (33, 4_099, 7, (0.0, 0.0), 0.3),             # barely above the blocked engine's minimum length
+])
+def test_pair_sweep_equals_oracle_and_generic_sweep(O, H, K, T, seed, silent_mean, sigma, monkeypatch):
+    import torch
+    y, sm, mu = _pair_case(H, K, T, seed, silent_mean)
+    xo, llo = O.viterbi(y, to_oracle_sm(O, sm), mu, sigma)
+    assert np.count_nonzero(xo > 1 + 2 * (K - 1)) > 0                      # pair states on the path
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for mode in ("pair", "generic"):
+        if mode == "generic":
+            monkeypatch.setenv("HMMSORT_PAIR", "0")
+        plan = H.Plan(T, sm, mu, sigma)
+        dy = torch.from_numpy(y).cuda()
+        dx = torch.zeros(T, dtype=torch.int16, device="cuda")
+        dll = torch.zeros(1, dtype=torch.float64, device="cuda")
+        plan.viterbi(dy, dx, dll, st)
+        res[mode] = (dx.cpu().numpy(), float(dll.cpu()[0]), plan.diagnostics(st))
+        plan.close()
+    monkeypatch.delenv("HMMSORT_PAIR", raising=False)
+    for mode, (x, ll, d) in res.items():
+        assert d[0] == 0, (mode, d)                                         # every block boundary certified
+        nbad = int(np.count_nonzero(x != xo))
+        assert nbad == 0, "%s sweep: path differs at %d samples, first at %d (diag %s)" % (
+            mode, nbad, int(np.argmax(x != xo)), d)
+        assert abs(ll - llo) <= LL_RTOL * abs(llo)
+    assert res["pair"][2][7] == 0, res["pair"][2]                           # no near-tie on the decoded path
+
+
+def test_pair_sweep_duplicate_templates_fall_back(O, H):
+    # twins: every spike is a tie that only the reference's operation order settles; the pair sweep flags the
+    # decisions on the path, hmmsort_viterbi decodes again with the generic blocked sweep and then the strict engine
+    K, T = 30, 30_000
+    t1 = H.create_spike_template(K, 3.0, 0.8, 0.2)
+    temps = np.asfortranarray(np.stack([t1, t1], 1))
+    pp = [0.004, 0.004]
+    sm = H.StateMatrix.create(2, K, np.log(pp), True)
+    y = H.create_signal(T, 0.3, pp, temps, seed=9)
+    H.set_option("engine", H.ENGINE_AUTO)
+    x, ll = H.viterbi(y, sm, temps, 0.3)
+    xo, llo = O.viterbi(y, to_oracle_sm(O, sm), temps, 0.3)
+    assert H.get_option("last_escalations") >= 1
+    assert np.array_equal(x, xo) and abs(ll - llo) <= LL_RTOL * abs(llo)
