@@ -891,7 +891,7 @@ int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t
         (rc = dalloc(&g->d_fmap, nb * S, &g->bytes)) || (rc = dalloc(&g->d_merged, nb, &g->bytes)) ||
         (rc = dalloc(&g->d_endstate, nb, &g->bytes)) || (rc = dalloc(&g->d_fconst, nb, &g->bytes)) || (rc = dalloc(&g->d_llpart, 3 * nb, &g->bytes)) ||
         (rc = dalloc(&g->d_bdiag, 8, &g->bytes)) || (rc = dalloc(&g->d_gapmin, nb, &g->bytes)) ||
-        (rc = dalloc(&g->d_frame, 2 * nb, &g->bytes)) || (rc = dalloc(&g->d_qsum, nb + 64, &g->bytes)))   // [0] sum y^2 of the pair sweep, [8..] its trash line
+        (rc = dalloc(&g->d_frame, 2 * nb, &g->bytes)) || (rc = dalloc(&g->d_qsum, 8, &g->bytes)))   // [0] sum y^2 of the pair sweep
         return rc;
     HS_HIP(hipMemset(g->d_frame, 0, 2 * nb * sizeof(double)));
     if (!g->blk_cols_lds && !g->blk_onecol && (rc = dalloc(&g->d_blkbuf, nb * 2 * S, &g->bytes)))

@@ -54,7 +54,6 @@ struct PairArgs {
     int16_t *T2c;
     double *endv, *warmv;
     double *qsum;          // [0]: sum over the recording of (y - m0)^2, for the near-tie threshold
-    int16_t *trash;        // 192 entries: where warm-up steps and idle lanes store
 };
 
 // Host: is this transition list the two-template overlap pattern, with the values the sweep assumes?
@@ -185,6 +184,11 @@ __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
     // this lane's columns: it WRITES column k (entries of the pair runs it starts), it READS column L - lane
     const int wcol = (on && k <= L - 1) ? CB[k] : 0, wmsk = (on && k <= L - 1) ? CB[64 + k] : 0;
     const int rcol = has_exit ? CB[dex] : 0, rmsk = has_exit ? CB[64 + dex] : 0;
+    const int rposb = has_exit ? rcol : CB[1];      // EBA has no column 0
+    // per-lane constants of the two-way decisions: first candidate's log-probability, ids of both candidates
+    const double c1A_r = lane == 0 ? c0A : cAA, c1B_r = lane == 0 ? c0B : cBB;
+    const int id1A = lane == 0 ? 1 : idA - 1, id2A = lane == 0 ? idBL : idPA;
+    const int id1B = lane == 0 ? 1 : idB - 1, id2B = lane == 0 ? idAL : idPB;
     // virtual entries: every pair state is present in the first column with its emission (viterbi.jl:55-63; the
     // flat start of a warm-up alike).  The pair (d + n + 1, n + 1) "entered" n samples before w; its entry holds
     // the part of CC that lies before w, so that exits and materialised columns come out right.
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
     {
         const double u = a.y[w] - m0;
         const double gA = on ? ((2.0 * u - ak) * akr) : 0.0, gB = on ? ((2.0 * u - bk) * bkr) : 0.0;
-        dA = gA; dB = gB; sA = gA; sB = gB;
+        dA = gA; dB = gB; sA = gA; sB = gB;   // (idle lanes: zero deviations, zero gains)
         const double q0 = a.c0 - (u * u) * rden;
         D0 = (w == 0) ? -q0 : 0.0;            // T1[1,1] = 0 (viterbi.jl:63) in the frame that drops c0 + q0 per sample
     }
@@ -243,15 +247,17 @@ __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
             dump(a.warmv + (int64_t)c * S, t - 1);
         }
         const double u = yt - m0;
-        const double gA = on ? ((2.0 * u - ak) * akr) : 0.0, gB = on ? ((2.0 * u - bk) * bkr) : 0.0;
-        // values of the previous sample: own lane, lane k-1, lane L
-        const double pdA = lane_prev(dA, 0.0), pdB = lane_prev(dB, 0.0);
+        // (idle lanes beyond phase L compute along with zero deviations; nothing reads them: shifts move values to
+        // HIGHER lanes only and the broadcasts read lane L-1)
+        const double gA = (2.0 * u - ak) * akr, gB = (2.0 * u - bk) * bkr;
+        // values of the previous sample: lane k-1 (lane 0: the silent state), lane L
+        const double pdA = lane_prev(dA, D0), pdB = lane_prev(dB, D0);
         const double psA = lane_prev(sA, 0.0), psB = lane_prev(sB, 0.0);
         const double dAL = pair_bcast(dA, L - 1), dBL = pair_bcast(dB, L - 1);
         const double sAL = pair_bcast(sA, L - 1), sBL = pair_bcast(sB, L - 1);
         // pair runs that end now (entered lane steps ago by lane L-k+1 of the other track)
         const int rpos = rcol + (((int)t - lane) & rmsk);          // (lanes without an exit read slot 0 of column 0: unused)
-        const double xa = ((EBA[has_exit ? rpos : CB[1]] + sBL) + psA) - CCba_r;      // P(k-1, L) at t-1
+        const double xa = ((EBA[rposb + (((int)t - lane) & rmsk)] + sBL) + psA) - CCba_r;      // P(k-1, L) at t-1
         const double xb = ((EAB[rpos] + sAL) + psB) - CCab_r;      // P(L, k-1) at t-1
         const double xp = ((EAB[(int)((t - L) & msk0)] + sAL) + sBL) - CC0;   // P(L, L) at t-1 (wave-uniform)
         // entries of this sample (from the previous sample's singles)
@@ -260,15 +266,13 @@ __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
             EAB[wpos] = (dA + cAP) - sA; EBA[wpos] = (dB + cBP) - sB;
         }
         if (lane == 0) EAB[(int)(t & msk0)] = D0 + c0P;
-        // decisions, list order = source index ascending, strict '>' (viterbi.jl:74-84)
-        double c1a, c2a, c1b, c2b;
-        if (lane == 0) { c1a = D0 + c0A; c2a = dBL + cBA; c1b = D0 + c0B; c2b = dAL + cAB; }
-        else { c1a = pdA + cAA; c2a = xa; c1b = pdB + cBB; c2b = xb; }
-        // B_1 <- {silent, A_L}: A_L (index 1+L) comes after silent; A_1 <- {silent, B_L} likewise
+        // decisions, list order = source index ascending, strict '>' (viterbi.jl:74-84): A_k <- {A_(k-1), P(k-1,L)},
+        // A_1 <- {silent, B_L}, B alike (the first candidate's constant and both ids are per-lane registers)
+        const double c1a = pdA + c1A_r, c1b = pdB + c1B_r;
+        const double c2a = lane == 0 ? dBL + cBA : xa, c2b = lane == 0 ? dAL + cAB : xb;
         const bool wa = c2a > c1a, wb = c2b > c1b;
         const double nA = (wa ? c2a : c1a) + gA, nB = (wb ? c2b : c1b) + gB;
-        const int argA = lane == 0 ? (wa ? idBL : 1) : (wa ? idPA : idA - 1);
-        const int argB = lane == 0 ? (wb ? idAL : 1) : (wb ? idPB : idB - 1);
+        const int argA = wa ? id2A : id1A, argB = wb ? id2B : id1B;
         double best = D0 + c00, sec = -INFINITY;   // margin of the winner over the runner-up (losers may tie freely)
         int arg0 = 1;
         {
@@ -278,18 +282,17 @@ __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
             if (xp > best) { sec = best; best = xp; arg0 = idPLL; } else sec = fmax(sec, xp);
         }
         const double g0 = best - sec;
-        {   // straight-line stores (warm-up steps and idle lanes write a trash line): stores under divergent
-            // branches make hipcc wait for vmcnt(0) every step, i.e. for the previous step's stores to reach L2
+        if (own) {   // (no vector-memory load inside the step loop, so these stores never make a step wait)
             int16_t *psi = a.T2c + (int64_t)a.nms * t;
-            const bool st = own && on;
-            *(st ? psi + k : a.trash + lane) = (int16_t)(argA | (fabs(c2a - c1a) < thr ? 0x8000 : 0));
-            *(st ? psi + L + k : a.trash + 64 + lane) = (int16_t)(argB | (fabs(c2b - c1b) < thr ? 0x8000 : 0));
-            *((own && lane == 0) ? psi : a.trash + 128 + lane) = (int16_t)(arg0 | (g0 < thr ? 0x8000 : 0));
+            if (on) {
+                psi[k] = (int16_t)(argA | (fabs(c2a - c1a) < thr ? 0x8000 : 0));
+                psi[L + k] = (int16_t)(argB | (fabs(c2b - c1b) < thr ? 0x8000 : 0));
+            }
+            if (lane == 0) psi[0] = (int16_t)(arg0 | (g0 < thr ? 0x8000 : 0));
         }
         D0 = best;
-        dA = on ? nA : 0.0; dB = on ? nB : 0.0;
-        sA = on ? psA + gA : 0.0; sB = on ? psB + gB : 0.0;
-        if (lane == 0) { sA = gA; sB = gB; }
+        dA = nA; dB = nB;
+        sA = psA + gA; sB = psB + gB;
         // (LDS operations of one wavefront execute in order: the next sample's reads see this sample's entries)
       }
     }
@@ -362,7 +365,6 @@ int pair_sweep_launch(GenericDev *g, const double *d_y, hipStream_t st)
     a.c0 = -kLog2Pi - g->lsig;
     a.den = 2.0 * (g->sigma * g->sigma);
     a.T2c = g->d_T2; a.endv = g->d_endv; a.warmv = g->d_warmv; a.qsum = g->d_qsum;
-    a.trash = reinterpret_cast<int16_t *>(g->d_qsum + 8);   // d_qsum has nblk >= ... doubles; see blocked_create
     HS_HIP(hipMemsetAsync(g->d_qsum, 0, sizeof(double), st));
     hipLaunchKernelGGL(k_pair_mag, dim3((unsigned)std::min<int64_t>(1024, (g->T + 255) / 256)), dim3(256), 0, st, d_y, g->T,
                        g->d_pairtab, g->d_qsum);
