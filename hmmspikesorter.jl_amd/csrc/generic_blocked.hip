@@ -612,10 +612,27 @@ __global__ __launch_bounds__(256) void k_block_map(const int16_t *__restrict__ T
                 mrg = lo - 1;
                 x[lo - 1] = (int16_t)cur;
             }
-        } else if (tid == 0) {
-            for (int r = n - 1; r >= 0; r--) {
-                cur = back_step(bt, rows + r * nms, cur);
-                x[lo + r - 1] = (int16_t)cur;
+        } else if (tid < 64) {
+            // The single walker: two dependent LDS reads per sample.  Most samples sit in the silent state and stay
+            // there: bit r of `stay` says that at row r the silent state's pointer is the silent state, and the walker
+            // crosses such a stretch without touching the rows again (n <= 64 rows are staged at a time).
+            const int m0 = bt[0] <= 0 ? -bt[0] : -1;
+            const bool st = m0 >= 0 && tid < n && ((int)rows[tid * nms + m0] & 0x7fff) == 1;
+            const unsigned long long stay = __ballot(st);
+            if (tid == 0) {
+                int r = n - 1;
+                while (r >= 0) {
+                    if (cur == 1) {
+                        int run = __clzll((long long)~(stay << (63 - r)));   // rows r, r-1, ... that stay silent
+                        run = run > r + 1 ? r + 1 : run;
+                        for (int q = 0; q < run; q++) x[lo + r - q - 1] = 1;
+                        r -= run;
+                        if (r < 0) break;
+                    }
+                    cur = back_step(bt, rows + r * nms, cur);
+                    x[lo + r - 1] = (int16_t)cur;
+                    r--;
+                }
             }
         }
     }
