@@ -165,3 +165,32 @@ def test_reference_baum_welch_testset(H):
         if cc[0] / np.sum(temps[:, 0] ** 2) < 0.01 and cc[1] / np.sum(temps[:, 1] ** 2) < 0.01:
             ok += 1
     assert ok >= len(seeds) - 1, "%d of %d seeds ended with the two generating templates" % (ok, len(seeds))
+
+
+def test_em_session_survives_a_list_that_loses_entry_transitions(H):
+    # the M-step of a wave plan always writes N entry log-probabilities; the host session must size its
+    # output from the library (hmmsort_plan_mstep_len), not from the current list, whose transitions leaving state 1
+    # shrink when a template's entry probability becomes -Inf (types.jl:121)
+    from hmmsort_amd.api import _EMSession
+    K, N, T = 30, 3, 40_000
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, 3.0, 0.8, 0.2),
+                                        H.create_spike_template(K, 4.0, 0.3, 0.2),
+                                        H.create_spike_template(K, 2.5, 0.6, 0.25)], 1))
+    pp = [0.004, 0.002, 0.003]
+    y = H.create_signal(T, 0.3, pp, temps, seed=6)
+    ses = _EMSession(y)
+    try:
+        sm = H.StateMatrix.create(N, K, np.log(pp), False)
+        sm1, mu1, s1 = ses.step(sm, temps.copy(order="F"), 0.35)
+        lp = np.log(pp)
+        lp[1] = -np.inf
+        dead = H.StateMatrix.create(N, K, lp, False)
+        assert len(dead.transitions) < len(sm.transitions)
+        assert ses.plan.mstep_len() == K * N + 1 + N + sm.nstates
+        sm2, mu2, s2 = ses.step(dead, mu1.copy(order="F"), s1)
+        assert len(sm2.pi) == sm.nstates and np.isfinite(s2)
+        fresh = H.train_step(y, dead, mu1.copy(order="F"), s1)
+        fin = np.isfinite(fresh[1])
+        assert np.allclose(mu2[fin], fresh[1][fin], rtol=1e-12, atol=1e-14) and abs(s2 - fresh[2]) <= 1e-12 * s2
+    finally:
+        ses.close()

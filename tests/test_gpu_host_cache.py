@@ -218,3 +218,53 @@ def test_strict_fallback_that_does_not_fit_returns_the_time_parallel_path(H):
     assert abs(ll1 - ll0) <= 1e-9 * abs(ll0)
     # the two paths agree except for which of the twin rings carries a spike
     assert np.array_equal(x0 > 1, x1 > 1)
+
+
+def test_cached_slot_is_resized_when_the_list_changes(O, H):
+    # the slot key holds neither R nor the engine.  Two overlap models with the same state table but a
+    # different number of finite entry log-probabilities (the reference drops -Inf transitions, types.jl:121) need
+    # statistics / output buffers of different lengths.  Every step must equal the step of a fresh plan, whatever
+    # the cache held before.  (hmmsort_em_step is called directly: rebuilding a StateMatrix from the dead model's
+    # shortened lp fails in the reference too -- isvalid_transition indexes lp[2].)
+    import ctypes as C
+    from conftest import to_oracle_sm
+    from hmmsort_amd._lib import check, lib, ptr, TRANS_DTYPE
+    K, T = 20, 30_000
+    t1 = H.create_spike_template(K, 3.0, 0.8, 0.2)
+    t2 = H.create_spike_template(K, 4.0, 0.3, 0.2)
+    temps = np.asfortranarray(np.stack([t1, t2], 1))
+    y = H.create_signal(T, 0.3, [0.004, 0.002], temps, seed=12)
+    full = H.StateMatrix.create(2, K, np.log([0.004, 0.002]), True)
+    dead = H.StateMatrix.create(2, K, np.array([np.log(0.004), -np.inf]), True)   # neuron 2 cannot start
+    assert len(dead.transitions) < len(full.transitions)
+
+    def em_step(sm):
+        st = np.asfortranarray(sm.states, dtype=np.int16)
+        tr = np.ascontiguousarray(sm.transitions, dtype=TRANS_DTYPE)
+        mu = temps.copy(order="F")
+        sig, nlp = C.c_double(0.0), C.c_int64(0)
+        lp, pp = np.zeros(len(tr)), np.zeros(sm.nstates)
+        check(lib().hmmsort_em_step(ptr(y), len(y), ptr(st), sm.N, sm.K, sm.nstates, ptr(tr), len(tr), ptr(mu), 0.35,
+                                    C.cast(C.byref(sig), C.c_void_p), ptr(lp), len(lp), C.byref(nlp), ptr(pp)))
+        return mu, sig.value, lp[:nlp.value].copy(), pp
+
+    models = [full, dead, full, dead]
+    H.set_option("plan_cache", 0)
+    ref = [em_step(sm) for sm in models[:2]]
+    assert len(ref[0][2]) == 3 and len(ref[1][2]) == 1        # xb[2:end]: one entry per transition leaving state 1 but the first
+    H.set_option("plan_cache", 4)
+    try:
+        for i, sm in enumerate(models):
+            mu1, s1, lp1, pp1 = em_step(sm)
+            mu0, s0, lp0, pp0 = ref[i % 2]
+            fin = np.isfinite(mu0)
+            # (the dead model's unreachable states turn the reference's update() into NaN: logsumexpl(-Inf, -Inf);
+            # what is compared is cached against fresh, bit for bit, NaN for NaN)
+            assert np.array_equal(np.isfinite(mu1), fin) and np.array_equal(mu1[fin], mu0[fin]), i
+            assert s1 == s0 or (np.isnan(s1) and np.isnan(s0)), i
+            assert np.array_equal(lp1, lp0, equal_nan=True) and np.array_equal(pp1, pp0, equal_nan=True)
+        # and the live model's step is the oracle's
+        _, omu, osig, _, _ = O.train_step(y, to_oracle_sm(O, full), temps.copy(order="F"), 0.35)
+        assert np.allclose(ref[0][0], omu, rtol=1e-6, atol=1e-9) and abs(ref[0][1] - osig) <= 1e-6 * osig
+    finally:
+        H.shutdown()
