@@ -557,7 +557,11 @@ __device__ __forceinline__ int back_step(const int32_t *bt, const int16_t *row, 
 // writes it to x and merged[c] records the last sample written (c*B-1 when nothing was).
 // fconst[c] = state at sample c*B-1 when it no longer depends on the end state (-1 otherwise, then
 // fmap[c][j] holds it for end state j+1).  Block 0 has no predecessor: fconst[0] = 1, unused.
-__global__ __launch_bounds__(256) void k_block_map(const int16_t *__restrict__ T2c,
+// BTM: where the per-state codes live -- 0 global (int32), 1 LDS (int32), 2 LDS as int16 (every code fits: sources are
+// state ids <= 32767, rows are minus an index below nms); with 2 a model of 21 123 states keeps its codes beside the
+// walkers and the staged rows (116 KB) instead of paying an L2 round trip per walker and sample.
+template <int BTM>
+__global__ __launch_bounds__(1024) void k_block_map(const int16_t *__restrict__ T2c,
                                                    const int32_t *__restrict__ btg, int nms, int W,
                                                    int bt_lds, int64_t T, int S, int B,
                                                    int16_t *__restrict__ fmap,
@@ -570,13 +574,22 @@ __global__ __launch_bounds__(256) void k_block_map(const int16_t *__restrict__ T
     int16_t *wk = lds16;                                  // S walkers
     int16_t *rows = wk + ((S + 3) & ~3);                  // W staged rows
     int32_t *btl = (int32_t *)(rows + ((W * nms + 3) & ~3));
+    int16_t *btl16 = (int16_t *)btl;
+    const int nth = blockDim.x;
     const int c = blockIdx.x, tid = threadIdx.x;
     const int64_t s = (int64_t)c * B;
     const int64_t e = (s + B < T) ? s + B : T;
-    if (bt_lds)
-        for (int j = tid; j < S; j += 256) btl[j] = btg[j];
-    const int32_t *bt = bt_lds ? btl : btg;
-    for (int j = tid; j < S; j += 256) wk[j] = (int16_t)(j + 1);
+    if (BTM == 1)
+        for (int j = tid; j < S; j += nth) btl[j] = btg[j];
+    if (BTM == 2)
+        for (int j = tid; j < S; j += nth) btl16[j] = (int16_t)btg[j];
+    const int32_t *bt = BTM == 1 ? btl : btg;
+    auto bstep = [&](const int16_t *row, int v) {
+        const int code = BTM == 2 ? (int)btl16[v - 1] : bt[v - 1];
+        return code > 0 ? code : ((int)row[-code] & 0x7fff);
+    };
+    auto bcode0 = [&]() { return BTM == 2 ? (int)btl16[0] : bt[0]; };
+    for (int j = tid; j < S; j += nth) wk[j] = (int16_t)(j + 1);
     bool one = (S == 1);
     int cur = 1;              // thread 0: the merged walker
     int64_t mrg = s - 1;      // last sample written to x
@@ -587,18 +600,18 @@ __global__ __launch_bounds__(256) void k_block_map(const int16_t *__restrict__ T
         const int n = (int)(hi - lo + 1);
         __syncthreads();
         const int16_t *src = T2c + (int64_t)nms * lo;
-        for (int i = tid; i < n * nms; i += 256) rows[i] = src[i];
+        for (int i = tid; i < n * nms; i += nth) rows[i] = src[i];
         __syncthreads();
         if (!one) {
-            for (int j = tid; j < S; j += 256) {
+            for (int j = tid; j < S; j += nth) {
                 int v = wk[j];
-                for (int r = n - 1; r >= 0; r--) v = back_step(bt, rows + r * nms, v);
+                for (int r = n - 1; r >= 0; r--) v = bstep(rows + r * nms, v);
                 wk[j] = (int16_t)v;
             }
             if (tid == 0) { mn = 32767; mx = 0; }
             __syncthreads();
             int l = 32767, h = 0;
-            for (int j = tid; j < S; j += 256) {
+            for (int j = tid; j < S; j += nth) {
                 const int v = wk[j];
                 l = v < l ? v : l;
                 h = v > h ? v : h;
@@ -616,7 +629,7 @@ __global__ __launch_bounds__(256) void k_block_map(const int16_t *__restrict__ T
             // The single walker: two dependent LDS reads per sample.  Most samples sit in the silent state and stay
             // there: bit r of `stay` says that at row r the silent state's pointer is the silent state, and the walker
             // crosses such a stretch without touching the rows again (n <= 64 rows are staged at a time).
-            const int m0 = bt[0] <= 0 ? -bt[0] : -1;
+            const int m0 = bcode0() <= 0 ? -bcode0() : -1;
             const bool st = m0 >= 0 && tid < n && ((int)rows[tid * nms + m0] & 0x7fff) == 1;
             const unsigned long long stay = __ballot(st);
             if (tid == 0) {
@@ -629,7 +642,7 @@ __global__ __launch_bounds__(256) void k_block_map(const int16_t *__restrict__ T
                         r -= run;
                         if (r < 0) break;
                     }
-                    cur = back_step(bt, rows + r * nms, cur);
+                    cur = bstep(rows + r * nms, cur);
                     x[lo + r - 1] = (int16_t)cur;
                     r--;
                 }
@@ -642,13 +655,13 @@ __global__ __launch_bounds__(256) void k_block_map(const int16_t *__restrict__ T
     if (one) {
         if (tid == 0) {
             merged[c] = mrg;
-            fconst[c] = (int16_t)((c > 0) ? back_step(bt, row_s, cur) : 1);
+            fconst[c] = (int16_t)((c > 0) ? bstep(row_s, cur) : 1);
         }
     } else {
         if (tid == 0) { merged[c] = s - 1; fconst[c] = (int16_t)((c > 0) ? -1 : 1); }
         if (c > 0)
-            for (int j = tid; j < S; j += 256)
-                fmap[(int64_t)c * S + j] = (int16_t)back_step(bt, row_s, wk[j]);
+            for (int j = tid; j < S; j += nth)
+                fmap[(int64_t)c * S + j] = (int16_t)bstep(row_s, wk[j]);
     }
 }
 
@@ -872,16 +885,30 @@ int blocked_set_model(GenericDev *g, const HostModel &m)
     // two-template overlap models: the sweep that treats pair runs as delays (pair_sweep.hip); its back-pointer
     // rows are the multi-source states silent, A_k, B_k in state order
     g->pair_ok = false;
+    g->multi_ok = false;
     if (!g->pair_off && !(getenv("HMMSORT_PAIR") && atoi(getenv("HMMSORT_PAIR")) == 0)) {
         std::vector<double> tab;
         const int64_t L = m.K - 1;
-        bool ok = pair_analyze(m, tab) && (int64_t)ms.size() == 2 * L + 1;
-        for (size_t q = 0; ok && q < ms.size(); q++) ok = ms[q].j == (int32_t)q;
+        bool ok = false, multi = false;
+        if (m.N == 2) {
+            ok = pair_analyze(m, tab) && (int64_t)ms.size() == 2 * L + 1;
+            for (size_t q = 0; ok && q < ms.size(); q++) ok = ms[q].j == (int32_t)q;
+        } else if (m.N >= 3 && m.N <= 5 && multi_lds_bytes((int)m.N, (int)L) <= 160 * 1024) {
+            // three to five templates (multi_sweep.hip): rows = Z, the singles, the pair entries, in state order
+            std::vector<int32_t> msj(ms.size());
+            for (size_t q = 0; q < ms.size(); q++) msj[q] = ms[q].j;
+            ok = multi = multi_rows_ok(m, msj) && multi_analyze(m, tab);
+        }
         if (ok) {
             int rc;
-            if (!g->d_pairtab && (rc = dalloc(&g->d_pairtab, tab.size(), &g->bytes))) return rc;
+            if (g->d_pairtab && g->pairtab_len < tab.size()) { (void)hipFree(g->d_pairtab); g->d_pairtab = nullptr; }
+            if (!g->d_pairtab) {
+                if ((rc = dalloc(&g->d_pairtab, tab.size(), &g->bytes))) return rc;
+                g->pairtab_len = tab.size();
+            }
             HS_HIP(hipMemcpy(g->d_pairtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
             g->pair_ok = true;
+            g->multi_ok = multi;
         }
     }
     return HMMSORT_OK;
@@ -975,7 +1002,7 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     int rc;
     const bool gcol = !g->blk_cols_lds, tl = g->blk_tail_lds;
     if (g->pair_ok) {
-        rc = pair_sweep_launch(g, d_y, st);
+        rc = g->multi_ok ? multi_sweep_launch(g, d_y, st) : pair_sweep_launch(g, d_y, st);
     } else if (g->blk_onecol) {
         const size_t lds1 = (size_t)(S + 1) * 8 + (size_t)g->ntail * 12 + 8;
         const int spt1 = (int)((S + 1023) / 1024);
@@ -1030,14 +1057,19 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     const int nms1 = std::max(g->nms, 1);
     int W = (int)std::max<int64_t>(1, std::min<int64_t>(64, (32 * 1024) / (nms1 * 2)));
     size_t lds_map = (size_t)((S + 3) & ~3) * 2 + (size_t)((W * g->nms + 3) & ~3) * 2;
-    const int bt_lds = lds_map + (size_t)S * 4 <= 150 * 1024;
-    if (bt_lds) lds_map += (size_t)S * 4;
-    if (lds_map > 64 * 1024)
-        HS_HIP(hipFuncSetAttribute((const void *)k_block_map,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_map));
-    hipLaunchKernelGGL(k_block_map, dim3(nb), dim3(256), lds_map, st, g->d_T2, g->d_bt, g->nms, W,
-                       bt_lds, T, (int)S, (int)g->B, g->d_fmap, g->d_fconst, g->d_merged, d_x);
-    HS_HIP(hipGetLastError());
+    const int btm = lds_map + (size_t)S * 4 <= 150 * 1024 ? 1 : (lds_map + (size_t)S * 2 + 8 <= 150 * 1024 ? 2 : 0);
+    if (btm == 1) lds_map += (size_t)S * 4;
+    if (btm == 2) lds_map += (size_t)S * 2 + 8;
+    const int map_threads = S > 8192 ? 1024 : 256;
+    auto go_map = [&](auto kern) -> int {
+        if (lds_map > 64 * 1024)
+            HS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_map));
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(map_threads), lds_map, st, g->d_T2, g->d_bt, g->nms, W,
+                           btm, T, (int)S, (int)g->B, g->d_fmap, g->d_fconst, g->d_merged, d_x);
+        HS_HIP(hipGetLastError());
+        return HMMSORT_OK;
+    };
+    if ((rc = btm == 1 ? go_map(k_block_map<1>) : (btm == 2 ? go_map(k_block_map<2>) : go_map(k_block_map<0>)))) return rc;
     hipLaunchKernelGGL(k_block_compose, dim3(1), dim3(256), 0, st, g->d_endv, g->d_fmap, g->d_fconst,
                        (int)S, nb, g->d_endstate);
     HS_HIP(hipGetLastError());
@@ -1055,7 +1087,7 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
 }
 
 bool generic_pair_active(const GenericDev *g) { return g && g->blocked && g->pair_ok; }
-void generic_pair_disable(GenericDev *g) { g->pair_off = true; g->pair_ok = false; }
+void generic_pair_disable(GenericDev *g) { g->pair_off = true; g->pair_ok = false; g->multi_ok = false; }
 
 int blocked_diagnostics(GenericDev *g, hipStream_t st, int64_t diag[8])
 {

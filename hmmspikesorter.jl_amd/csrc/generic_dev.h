@@ -42,6 +42,8 @@ struct GenericDev {
     double *d_frame = nullptr;  // per block: frame constant relative to the previous block, |values|
     // structure-exploiting sweep for two-template overlap models (pair_sweep.hip)
     bool pair_ok = false, pair_off = false;   // pair_off: the host fell back to the generic sweep for this plan
+    bool multi_ok = false;                    // pair_ok through the 3-5 template sweep (multi_sweep.hip)
+    size_t pairtab_len = 0;
     double *d_pairtab = nullptr, *d_qsum = nullptr;
     // time-parallel E-step (generic_estep.hip), allocated on first use
     double *d_es_win = nullptr, *d_es_rec = nullptr, *d_es_partG = nullptr, *d_es_partX = nullptr;
@@ -58,6 +60,12 @@ int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t
 bool pair_analyze(const HostModel &m, std::vector<double> &tab);
 int pair_sweep_launch(GenericDev *g, const double *d_y, hipStream_t st);
 int pair_ties_launch(GenericDev *g, const int16_t *d_x, hipStream_t st);
+int pair_mag_launch(GenericDev *g, const double *d_y, hipStream_t st);
+// multi_sweep.hip (three to five templates)
+bool multi_analyze(const HostModel &m, std::vector<double> &tab);
+bool multi_rows_ok(const HostModel &m, const std::vector<int32_t> &ms_states);
+size_t multi_lds_bytes(int N, int L);
+int multi_sweep_launch(GenericDev *g, const double *d_y, hipStream_t st);
 int blocked_set_model(GenericDev *g, const HostModel &m);
 void blocked_destroy(GenericDev *g);
 int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll, hipStream_t st);

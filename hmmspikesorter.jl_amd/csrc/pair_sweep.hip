@@ -50,6 +50,7 @@ struct PairArgs {
     int64_t T;
     int S, B, H, L, nms;
     const double *tab;
+    const double *mean;    // [S] per-state means (first decisions of a recording: reference arithmetic)
     double c0, den;
     int16_t *T2c;
     double *endv, *warmv;
@@ -282,13 +283,32 @@ __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
             if (xp > best) { sec = best; best = xp; arg0 = idPLL; } else sec = fmax(sec, xp);
         }
         const double g0 = best - sec;
+        int wpA = argA | (fabs(c2a - c1a) < thr ? 0x8000 : 0), wpB = argB | (fabs(c2b - c1b) < thr ? 0x8000 : 0);
+        int wp0 = arg0 | (g0 < thr ? 0x8000 : 0);
+        if (w == 0 && t == 1) {
+            // The first decisions of a recording compare emission-only values (viterbi.jl:55-63), and the states whose
+            // deviation is ~0 (the last phases of both templates, P(L,L)) tie there to the last bit: these decisions are
+            // taken in the reference's own arithmetic, T1[k,1] + lp with strict '>' in list order (viterbi.jl:74-84).
+            const double y0 = a.y[0];
+            auto fex = [&](int id1) { const double dd = y0 - a.mean[id1 - 1]; return a.c0 - (dd * dd) / a.den; };
+            const double e1a = (lane == 0 ? 0.0 : fex(on ? id1A : 1)) + c1A_r, e2a = fex(on ? id2A : 1) + (lane == 0 ? cBA : 0.0);
+            const double e1b = (lane == 0 ? 0.0 : fex(on ? id1B : 1)) + c1B_r, e2b = fex(on ? id2B : 1) + (lane == 0 ? cAB : 0.0);
+            wpA = e2a > e1a ? id2A : id1A;
+            wpB = e2b > e1b ? id2B : id1B;
+            double bv = 0.0 + c00;
+            wp0 = 1;
+            const double z1 = fex(idAL) + cA0, z2 = fex(idBL) + cB0, z3 = fex(idPLL) + 0.0;
+            if (z1 > bv) { bv = z1; wp0 = idAL; }
+            if (z2 > bv) { bv = z2; wp0 = idBL; }
+            if (z3 > bv) { bv = z3; wp0 = idPLL; }
+        }
         if (own) {   // (no vector-memory load inside the step loop, so these stores never make a step wait)
             int16_t *psi = a.T2c + (int64_t)a.nms * t;
             if (on) {
-                psi[k] = (int16_t)(argA | (fabs(c2a - c1a) < thr ? 0x8000 : 0));
-                psi[L + k] = (int16_t)(argB | (fabs(c2b - c1b) < thr ? 0x8000 : 0));
+                psi[k] = (int16_t)wpA;
+                psi[L + k] = (int16_t)wpB;
             }
-            if (lane == 0) psi[0] = (int16_t)(arg0 | (g0 < thr ? 0x8000 : 0));
+            if (lane == 0) psi[0] = (int16_t)wp0;
         }
         D0 = best;
         dA = nA; dB = nB;
@@ -320,13 +340,20 @@ __global__ __launch_bounds__(256) void k_pair_mag(const double *__restrict__ y, 
 // flagged decisions on the decoded path: the state at sample t is a deciding state (silent, A_k, B_k) whose
 // back-pointer of that sample carries the flag.  (The final arg-max over the end states is the blocked engine's,
 // on columns materialised to ~1e-12: its margin is checked by k_pair_tail.)
+// (bt: the blocked engine's per-state code, <= 0 for a multi-source state = minus its row; null: row = state.)
 __global__ __launch_bounds__(256) void k_pair_ties(const int16_t *__restrict__ x, const int16_t *__restrict__ T2c,
-                                                   int64_t T, int nms, unsigned long long *diag)
+                                                   const int32_t *__restrict__ bt, int64_t T, int nms, unsigned long long *diag)
 {
     unsigned long long n = 0;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; t < T; t += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)x[t] - 1;
-        if (j < nms && (T2c[t * nms + j] & (int16_t)0x8000)) n++;
+        const int row = bt ? (bt[j] <= 0 ? -bt[j] : -1) : (j < nms ? j : -1);
+        if (row >= 0 && (T2c[t * nms + row] & (int16_t)0x8000)) {
+            n++;
+#ifdef HS_PAIR_DEBUG
+            printf("flag on path: t %lld state %d row %d psi %d prev %d\n", (long long)t, j + 1, row, (int)(T2c[t * nms + row] & 0x7fff), (int)x[t - 1]);
+#endif
+        }
     }
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(&diag[7], n);
@@ -353,8 +380,22 @@ __global__ __launch_bounds__(256) void k_pair_tail(const double *__restrict__ en
         }
         const double mmax = fabs(c0) * (double)T + qsum[0] / den + fabs(tab[0]) * (double)T + 1.0;
         const double thr = ldexp(16.0 * (double)(L + 2), ilogb(mmax) - 52) + 1e-10;
-        if (best - sec < thr) atomicAdd(&diag[7], 1ull);
+        if (best - sec < thr) {
+            atomicAdd(&diag[7], 1ull);
+#ifdef HS_PAIR_DEBUG
+            printf("tail margin %g thr %g best %g\n", best - sec, thr, best);
+#endif
+        }
     }
+}
+
+int pair_mag_launch(GenericDev *g, const double *d_y, hipStream_t st)
+{
+    HS_HIP(hipMemsetAsync(g->d_qsum, 0, sizeof(double), st));
+    hipLaunchKernelGGL(k_pair_mag, dim3((unsigned)std::min<int64_t>(1024, (g->T + 255) / 256)), dim3(256), 0, st, d_y, g->T,
+                       g->d_pairtab, g->d_qsum);
+    HS_HIP(hipGetLastError());
+    return HMMSORT_OK;
 }
 
 int pair_sweep_launch(GenericDev *g, const double *d_y, hipStream_t st)
@@ -362,12 +403,12 @@ int pair_sweep_launch(GenericDev *g, const double *d_y, hipStream_t st)
     PairArgs a;
     a.y = d_y; a.T = g->T; a.S = (int)g->S; a.B = (int)g->B; a.H = (int)g->H; a.L = (int)g->K - 1; a.nms = g->nms;
     a.tab = g->d_pairtab;
+    a.mean = g->d_mean;
     a.c0 = -kLog2Pi - g->lsig;
     a.den = 2.0 * (g->sigma * g->sigma);
     a.T2c = g->d_T2; a.endv = g->d_endv; a.warmv = g->d_warmv; a.qsum = g->d_qsum;
-    HS_HIP(hipMemsetAsync(g->d_qsum, 0, sizeof(double), st));
-    hipLaunchKernelGGL(k_pair_mag, dim3((unsigned)std::min<int64_t>(1024, (g->T + 255) / 256)), dim3(256), 0, st, d_y, g->T,
-                       g->d_pairtab, g->d_qsum);
+    int rc = pair_mag_launch(g, d_y, st);
+    if (rc) return rc;
     const int L_ = (int)g->K - 1;
     const size_t lds = (size_t)(2 * pairbase(L_, L_) - pairfifo(L_, 0) + 64) * sizeof(double) + 128 * sizeof(int);
     HS_HIP(hipFuncSetAttribute((const void *)pair_vit_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -379,7 +420,7 @@ int pair_sweep_launch(GenericDev *g, const double *d_y, hipStream_t st)
 int pair_ties_launch(GenericDev *g, const int16_t *d_x, hipStream_t st)
 {
     hipLaunchKernelGGL(k_pair_ties, dim3((unsigned)std::min<int64_t>(2048, (g->T + 255) / 256)), dim3(256), 0, st, d_x,
-                       g->d_T2, g->T, g->nms, g->d_bdiag);
+                       g->d_T2, g->multi_ok ? g->d_bt : nullptr, g->T, g->nms, g->d_bdiag);
     hipLaunchKernelGGL(k_pair_tail, dim3(1), dim3(256), 0, st, g->d_endv + (g->nblk - 1) * g->S, (int)g->S, g->d_qsum,
                        g->d_pairtab, -kLog2Pi - g->lsig, 2.0 * (g->sigma * g->sigma), g->T, (int)g->K - 1, g->d_bdiag);
     HS_HIP(hipGetLastError());
