@@ -669,7 +669,7 @@ __global__ __launch_bounds__(1024) void k_block_map(const int16_t *__restrict__ 
 __global__ __launch_bounds__(256) void k_block_compose(const double *__restrict__ endv,
                                                        const int16_t *__restrict__ fmap,
                                                        const int16_t *__restrict__ fconst, int S,
-                                                       int nblk, int16_t *__restrict__ endstate)
+                                                       int nblk, int16_t *__restrict__ endstate, int chain)
 {
     __shared__ double bv[256];
     __shared__ int bi[256];
@@ -697,12 +697,91 @@ __global__ __launch_bounds__(256) void k_block_compose(const double *__restrict_
         // the reference's scan starts at state 1 and only moves on a strict '>': a NaN there stays
         int st = (bi[0] < S && last[0] == last[0] ? bi[0] : 0) + 1;
         endstate[nblk - 1] = (int16_t)st;
-        for (int c = nblk - 1; c >= 1; c--) {
+        for (int c = nblk - 1; c >= 1 && chain; c--) {
             const int f = fconst[c];
             st = f > 0 ? f : fmap[(int64_t)c * S + (st - 1)];
             endstate[c - 1] = (int16_t)st;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backtrace by segments (models with wide back-pointer rows: the overlap models of three and more templates keep
+// ~1 000 pointers per sample, and staging every row through LDS for ONE walker reads all of T2c).  The time axis is cut
+// into segments of SEG samples, one THREAD per segment: it starts WI samples above its segment in the silent state
+// (a guess), walks down -- one dependent 2-byte load per sample, thousands of walkers in flight hide the latency --
+// and writes its segment from the state it arrived with (guess[k]); below[k] is the state it implies for the last
+// sample of segment k-1.  The last segment starts from the arg-max (viterbi.jl:90).  Back-pointers are deterministic, so
+// the path is the reference's as soon as every boundary is consistent, guess[k] == below[k+1] for all k (induction from
+// the last segment); k_seg_fix re-walks a segment whose guess was wrong from the true state and stops where it meets
+// the path it wrote before; boundaries still open after the fix passes are counted in diag[0] (the host-buffer entry
+// points then fall back like for a failed warm-up certificate).  No assumption is made -- the check is exact.
+template <bool BTL>
+__device__ __forceinline__ int seg_back(const int16_t *__restrict__ T2c, const int32_t *__restrict__ btg,
+                                        const int16_t *btl, int nms, int64_t t, int v)
+{
+    const int code = BTL ? (int)btl[v - 1] : btg[v - 1];
+    return code > 0 ? code : ((int)T2c[t * nms - code] & 0x7fff);
+}
+
+template <bool BTL>
+__global__ __launch_bounds__(256) void k_seg_walk(const int16_t *__restrict__ T2c, const int32_t *__restrict__ btg,
+                                                  int nms, int64_t T, int S, int SEG, int WI, int nseg,
+                                                  const int16_t *__restrict__ laststate, int16_t *__restrict__ x,
+                                                  int16_t *__restrict__ guess, int16_t *__restrict__ below)
+{
+    extern __shared__ int16_t seg_bt[];
+    if (BTL) {
+        for (int j = threadIdx.x; j < S; j += 256) seg_bt[j] = (int16_t)btg[j];
+        __syncthreads();
+    }
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nseg) return;
+    const int64_t lo = (int64_t)k * SEG;
+    const int64_t hi = (lo + SEG < T ? lo + SEG : T) - 1;
+    int v;
+    if (k == nseg - 1) v = laststate[0];
+    else {
+        const int64_t t0 = hi + WI < T - 1 ? hi + WI : T - 1;
+        v = 1;
+        for (int64_t t = t0; t > hi; t--) v = seg_back<BTL>(T2c, btg, seg_bt, nms, t, v);
+    }
+    guess[k] = (int16_t)v;
+    for (int64_t t = hi; t >= lo; t--) {
+        x[t] = (int16_t)v;
+        if (t > 0) v = seg_back<BTL>(T2c, btg, seg_bt, nms, t, v);
+    }
+    below[k] = (int16_t)v;
+}
+
+template <bool BTL>
+__global__ __launch_bounds__(256) void k_seg_fix(const int16_t *__restrict__ T2c, const int32_t *__restrict__ btg,
+                                                 int nms, int64_t T, int S, int SEG, int nseg,
+                                                 int16_t *__restrict__ x, int16_t *__restrict__ guess,
+                                                 int16_t *__restrict__ below, int final_pass, unsigned long long *diag)
+{
+    extern __shared__ int16_t seg_bt[];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const bool todo = k < nseg - 1 && guess[k] != below[k + 1];
+    if (final_pass) {
+        if (todo) atomicAdd(&diag[0], 1ull);
+        return;
+    }
+    if (!__syncthreads_or(todo)) return;
+    if (BTL) {
+        for (int j = threadIdx.x; j < S; j += 256) seg_bt[j] = (int16_t)btg[j];
+        __syncthreads();
+    }
+    if (!todo) return;
+    int v = below[k + 1];
+    guess[k] = (int16_t)v;
+    const int64_t lo = (int64_t)k * SEG, hi = lo + SEG - 1;
+    for (int64_t t = hi; t >= lo; t--) {
+        if (x[t] == (int16_t)v) return;        // met the path written before: everything below is unchanged
+        x[t] = (int16_t)v;
+        if (t > 0) v = seg_back<BTL>(T2c, btg, seg_bt, nms, t, v);
+    }
+    below[k] = (int16_t)v;
 }
 
 // the part of each block's path above the merge point
@@ -947,7 +1026,7 @@ int blocked_create(GenericDev *g, const HostModel &m, int64_t block_req, int64_t
 void blocked_destroy(GenericDev *g)
 {
     void *ptrs[] = {g->d_lp0, g->d_src0, g->d_tinfo, g->d_tsrc, g->d_tlp, g->d_endv, g->d_warmv,
-                    g->d_fmap, g->d_merged, g->d_endstate, g->d_llpart, g->d_bdiag, g->d_blkbuf, g->d_ms, g->d_bt, g->d_fconst, g->d_lpdict, g->d_lpidx, g->d_gapmin, g->d_frame, g->d_pairtab, g->d_qsum};
+                    g->d_fmap, g->d_merged, g->d_endstate, g->d_llpart, g->d_bdiag, g->d_blkbuf, g->d_ms, g->d_bt, g->d_fconst, g->d_lpdict, g->d_lpidx, g->d_gapmin, g->d_frame, g->d_pairtab, g->d_qsum, g->d_segbuf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -1053,29 +1132,57 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
         hipLaunchKernelGGL(k_block_ties, dim3(1), dim3(64), 0, st, g->d_frame, g->d_gapmin, nb, g->d_bdiag);
         HS_HIP(hipGetLastError());
     }
-    // backtrace: rows of T2c staged W at a time; bt in LDS when it fits
-    const int nms1 = std::max(g->nms, 1);
-    int W = (int)std::max<int64_t>(1, std::min<int64_t>(64, (32 * 1024) / (nms1 * 2)));
-    size_t lds_map = (size_t)((S + 3) & ~3) * 2 + (size_t)((W * g->nms + 3) & ~3) * 2;
-    const int btm = lds_map + (size_t)S * 4 <= 150 * 1024 ? 1 : (lds_map + (size_t)S * 2 + 8 <= 150 * 1024 ? 2 : 0);
-    if (btm == 1) lds_map += (size_t)S * 4;
-    if (btm == 2) lds_map += (size_t)S * 2 + 8;
-    const int map_threads = S > 8192 ? 1024 : 256;
-    auto go_map = [&](auto kern) -> int {
-        if (lds_map > 64 * 1024)
-            HS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_map));
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(map_threads), lds_map, st, g->d_T2, g->d_bt, g->nms, W,
-                           btm, T, (int)S, (int)g->B, g->d_fmap, g->d_fconst, g->d_merged, d_x);
+    if (g->nms >= 64 && S > 1) {
+        // wide rows: backtrace by segments (k_seg_walk)
+        const int SEG = 256, WI = (int)std::max<int64_t>(256, 4 * (g->K - 1));
+        const int nseg = (int)((T + SEG - 1) / SEG);
+        if (!g->d_segbuf) {
+            if ((rc = dalloc(&g->d_segbuf, (size_t)2 * nseg + 2, &g->bytes))) return rc;
+        }
+        int16_t *guess = g->d_segbuf, *below = g->d_segbuf + nseg + 1;
+        hipLaunchKernelGGL(k_block_compose, dim3(1), dim3(256), 0, st, g->d_endv, g->d_fmap, g->d_fconst,
+                           (int)S, nb, g->d_endstate, 0);
         HS_HIP(hipGetLastError());
-        return HMMSORT_OK;
-    };
-    if ((rc = btm == 1 ? go_map(k_block_map<1>) : (btm == 2 ? go_map(k_block_map<2>) : go_map(k_block_map<0>)))) return rc;
-    hipLaunchKernelGGL(k_block_compose, dim3(1), dim3(256), 0, st, g->d_endv, g->d_fmap, g->d_fconst,
-                       (int)S, nb, g->d_endstate);
-    HS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_block_finish, dim3((nb + 63) / 64), dim3(64), 0, st, g->d_T2, g->d_bt, g->nms,
-                       T, (int)S, (int)g->B, nb, g->d_endstate, g->d_merged, d_x);
-    HS_HIP(hipGetLastError());
+        const bool btl = (size_t)S * 2 <= 64 * 1024;
+        const size_t lds_seg = btl ? (size_t)S * 2 : 0;
+        const dim3 gs((unsigned)((nseg + 255) / 256));
+        if (btl) hipLaunchKernelGGL(k_seg_walk<true>, gs, dim3(256), lds_seg, st, g->d_T2, g->d_bt, g->nms, T, (int)S, SEG, WI,
+                                    nseg, g->d_endstate + (nb - 1), d_x, guess, below);
+        else hipLaunchKernelGGL(k_seg_walk<false>, gs, dim3(256), 0, st, g->d_T2, g->d_bt, g->nms, T, (int)S, SEG, WI,
+                                nseg, g->d_endstate + (nb - 1), d_x, guess, below);
+        HS_HIP(hipGetLastError());
+        for (int pass = 0; pass <= 8; pass++) {
+            if (btl) hipLaunchKernelGGL(k_seg_fix<true>, gs, dim3(256), lds_seg, st, g->d_T2, g->d_bt, g->nms, T, (int)S, SEG,
+                                        nseg, d_x, guess, below, pass == 8, g->d_bdiag);
+            else hipLaunchKernelGGL(k_seg_fix<false>, gs, dim3(256), 0, st, g->d_T2, g->d_bt, g->nms, T, (int)S, SEG, nseg,
+                                    d_x, guess, below, pass == 8, g->d_bdiag);
+            HS_HIP(hipGetLastError());
+        }
+    } else {
+    // backtrace: rows of T2c staged W at a time; bt in LDS when it fits
+        const int nms1 = std::max(g->nms, 1);
+        int W = (int)std::max<int64_t>(1, std::min<int64_t>(64, (32 * 1024) / (nms1 * 2)));
+        size_t lds_map = (size_t)((S + 3) & ~3) * 2 + (size_t)((W * g->nms + 3) & ~3) * 2;
+        const int btm = lds_map + (size_t)S * 4 <= 150 * 1024 ? 1 : (lds_map + (size_t)S * 2 + 8 <= 150 * 1024 ? 2 : 0);
+        if (btm == 1) lds_map += (size_t)S * 4;
+        if (btm == 2) lds_map += (size_t)S * 2 + 8;
+        const int map_threads = S > 8192 ? 1024 : 256;
+        auto go_map = [&](auto kern) -> int {
+            if (lds_map > 64 * 1024)
+                HS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_map));
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(map_threads), lds_map, st, g->d_T2, g->d_bt, g->nms, W,
+                               btm, T, (int)S, (int)g->B, g->d_fmap, g->d_fconst, g->d_merged, d_x);
+            HS_HIP(hipGetLastError());
+            return HMMSORT_OK;
+        };
+        if ((rc = btm == 1 ? go_map(k_block_map<1>) : (btm == 2 ? go_map(k_block_map<2>) : go_map(k_block_map<0>)))) return rc;
+        hipLaunchKernelGGL(k_block_compose, dim3(1), dim3(256), 0, st, g->d_endv, g->d_fmap, g->d_fconst,
+                           (int)S, nb, g->d_endstate, 1);
+        HS_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_block_finish, dim3((nb + 63) / 64), dim3(64), 0, st, g->d_T2, g->d_bt, g->nms,
+                           T, (int)S, (int)g->B, nb, g->d_endstate, g->d_merged, d_x);
+        HS_HIP(hipGetLastError());
+    }
     if (g->pair_ok && (rc = pair_ties_launch(g, d_x, st))) return rc;   // flagged decisions ON the decoded path -> diag[7]
     hipLaunchKernelGGL(k_block_ll, dim3(nb), dim3(256), 0, st, d_y, d_x, T, (int)S, (int)g->B,
                        g->d_mean, g->d_in_ptr, g->d_in_src, g->d_in_lp, a.c0, a.den, g->d_llpart);

@@ -37,6 +37,7 @@ struct GenericDev {
     int ndict = 0;               // 0: more than 256 distinct values, dictionary unusable
     int nms = 0;
     int16_t *d_fmap = nullptr, *d_endstate = nullptr, *d_fconst = nullptr;
+    int16_t *d_segbuf = nullptr;   // guess | below of the segment backtrace
     int64_t *d_merged = nullptr;
     unsigned long long *d_bdiag = nullptr, *d_gapmin = nullptr;
     double *d_frame = nullptr;  // per block: frame constant relative to the previous block, |values|

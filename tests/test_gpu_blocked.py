@@ -284,3 +284,109 @@ def test_pair_sweep_duplicate_templates_fall_back(O, H):
     xo, llo = O.viterbi(y, to_oracle_sm(O, sm), temps, 0.3)
     assert H.get_option("last_escalations") >= 1
     assert np.array_equal(x, xo) and abs(ll - llo) <= LL_RTOL * abs(llo)
+
+
+# ---- three to five templates: tracks per neuron, pair runs as delays (csrc/multi_sweep.hip) ----
+def _multi_case(H, N, K, T, seed, silent_mean=0.0):
+    rng = np.random.default_rng(seed)
+    shapes = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15), (2.0, 0.4, 0.3)]
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, *shapes[i]) for i in range(N)], 1))
+    pp = [0.004, 0.002, 0.003, 0.0025, 0.002][:N]
+    pp = [p * min(1.0, 30.0 / K) for p in pp]
+    y = H.create_signal(T, 0.3, pp, temps, seed=seed)
+    L = K - 1
+    for _ in range(max(6, T // 3000)):          # overlapping pairs at random offsets, a third spike as the first ends
+        t0 = int(rng.integers(L, T - 4 * L))
+        d = int(rng.integers(0, L))
+        a, b = rng.choice(N, 2, replace=False)
+        y[t0:t0 + L] += temps[1:, a]
+        y[t0 + d:t0 + d + L] += temps[1:, b]
+        if rng.random() < 0.5:
+            c = int(rng.choice([q for q in range(N) if q != a]))
+            y[t0 + L:t0 + 2 * L] += temps[1:, c]
+    mu = temps.copy(order="F")
+    mu[0, :] = silent_mean
+    sm = H.StateMatrix.create(N, K, np.log(pp), True)
+    return y, sm, mu
+
+
+@pytest.mark.parametrize("N,K,T,seed,silent_mean,sigma", [
+    (3, 12, 30_000, 1, 0.0, 0.3),
+    (3, 25, 20_000, 2, 0.01, 0.35),              # nonzero silent means
+    (4, 16, 24_000, 3, 0.0, 0.3),
+    (4, 9, 12_000, 4, 0.0, 0.25),
+    (5, 10, 12_000, 5, 0.0, 0.3),
+    (3, 3, 6_000, 6, 0.0, 0.3),                  # two phases per ring
+    (4, 20, 4_099, 7, 0.0, 0.2),                 # barely above the blocked engine's minimum length; sigma < 0.4: the
+                                                 # path starts in a state whose deviation is ~0 (exact first decisions)
+])
+def test_multi_sweep_equals_oracle_and_generic_sweep(O, H, N, K, T, seed, silent_mean, sigma, monkeypatch):
+    import torch
+    y, sm, mu = _multi_case(H, N, K, T, seed, silent_mean)
+    xo, llo = O.viterbi(y, to_oracle_sm(O, sm), mu, sigma)
+    assert np.count_nonzero(xo > 1 + N * (K - 1)) > 0                      # pair states on the path
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for mode in ("multi", "generic"):
+        if mode == "generic":
+            monkeypatch.setenv("HMMSORT_PAIR", "0")
+        plan = H.Plan(T, sm, mu, sigma)
+        dy = torch.from_numpy(y).cuda()
+        dx = torch.zeros(T, dtype=torch.int16, device="cuda")
+        dll = torch.zeros(1, dtype=torch.float64, device="cuda")
+        plan.viterbi(dy, dx, dll, st)
+        res[mode] = (dx.cpu().numpy(), float(dll.cpu()[0]), plan.diagnostics(st))
+        plan.close()
+    monkeypatch.delenv("HMMSORT_PAIR", raising=False)
+    for mode, (x, ll, d) in res.items():
+        assert d[0] == 0, (mode, d)
+        nbad = int(np.count_nonzero(x != xo))
+        assert nbad == 0, "%s sweep: path differs at %d samples, first at %d (diag %s)" % (
+            mode, nbad, int(np.argmax(x != xo)), d)
+        assert abs(ll - llo) <= LL_RTOL * abs(llo)
+    assert res["multi"][2][7] == 0, res["multi"][2]                         # no near-tie on the decoded path
+    assert res["multi"][2][2] != res["generic"][2][2]                       # (the two sweeps are different code: their
+                                                                            # boundary residuals differ)
+
+
+def test_multi_sweep_cli_shape_equals_generic_sweep(H, monkeypatch):
+    # the largest model the reference's CLI builds (hmmsort.jl:50-54): 4 templates, K = 60, 21 123 states; the CPU
+    # oracle needs minutes here, the checker is the generic blocked sweep (itself oracle-checked above)
+    import torch
+    N, K, T = 4, 60, 400_000
+    y, sm, mu = _multi_case(H, N, K, T, 11)
+    assert sm.nstates == 21123
+    st = torch.cuda.current_stream().cuda_stream
+    dy = torch.from_numpy(y).cuda()
+    res = {}
+    for mode in ("multi", "generic"):
+        if mode == "generic":
+            monkeypatch.setenv("HMMSORT_PAIR", "0")
+        plan = H.Plan(T, sm, mu, 0.3)
+        dx = torch.zeros(T, dtype=torch.int16, device="cuda")
+        dll = torch.zeros(1, dtype=torch.float64, device="cuda")
+        plan.viterbi(dy, dx, dll, st)
+        res[mode] = (dx.cpu().numpy(), float(dll.cpu()[0]), plan.diagnostics(st))
+        plan.close()
+    monkeypatch.delenv("HMMSORT_PAIR", raising=False)
+    assert res["multi"][2][0] == 0 and res["multi"][2][7] == 0 and res["generic"][2][7] == 0, res
+    assert np.array_equal(res["multi"][0], res["generic"][0])
+    assert np.count_nonzero(res["multi"][0] > 1 + N * (K - 1)) > 0
+    assert abs(res["multi"][1] - res["generic"][1]) <= LL_RTOL * abs(res["generic"][1])
+
+
+def test_multi_sweep_duplicate_templates_fall_back(O, H):
+    # twins among three templates: ties that only the reference's operation order settles are flagged on the path and
+    # hmmsort_viterbi decodes again with the generic sweep / the strict engine
+    K, T = 14, 20_000
+    t1 = H.create_spike_template(K, 3.0, 0.8, 0.2)
+    t2 = H.create_spike_template(K, 4.0, 0.3, 0.2)
+    temps = np.asfortranarray(np.stack([t1, t2, t1], 1))
+    pp = [0.004, 0.003, 0.004]
+    sm = H.StateMatrix.create(3, K, np.log(pp), True)
+    y = H.create_signal(T, 0.3, pp, temps, seed=9)
+    H.set_option("engine", H.ENGINE_AUTO)
+    x, ll = H.viterbi(y, sm, temps, 0.3)
+    xo, llo = O.viterbi(y, to_oracle_sm(O, sm), temps, 0.3)
+    assert H.get_option("last_escalations") >= 1
+    assert np.array_equal(x, xo) and abs(ll - llo) <= LL_RTOL * abs(llo)
