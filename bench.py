@@ -637,12 +637,12 @@ def main():
     # ---- overlap-resolving decode: the reference's own Viterbi-test model,
     # test/runtests.jl:17-34 -- 2 templates, K=60, allow_overlaps=true, 3600 states -- through the
     # blocked engine, device-resident (untimed extra, rank 0 of a 1-GPU run only) ----
-    def overlap_decode(To=10_000_000):
+    def overlap_decode(To=10_000_000, No=2):
         Ko = 60
-        t2 = np.asfortranarray(np.stack([H.create_spike_template(Ko, 3.0, 0.8, 0.2),
-                                         H.create_spike_template(Ko, 4.0, 0.3, 0.2)], 1))
-        ppo = [0.003, 0.001]
-        smo = H.StateMatrix.create(2, Ko, np.log(ppo), True)
+        shapes = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)]
+        t2 = np.asfortranarray(np.stack([H.create_spike_template(Ko, *shapes[i]) for i in range(No)], 1))
+        ppo = [0.003, 0.001, 0.002, 0.0015][:No]
+        smo = H.StateMatrix.create(No, Ko, np.log(ppo), True)
         yo = torch.from_numpy(H.create_signal(To, sigma, ppo, t2, seed=seed + 7)).to(dev)
         xo = torch.zeros(To, dtype=torch.int16, device=dev)
         po = H.Plan(To, smo, t2, sigma)
@@ -655,11 +655,15 @@ def main():
         per = (time.perf_counter() - t) / 3
         d = po.diagnostics(stream)
         po.close()
-        return {"model": "N=2 K=%d allow_overlaps=true, %d states" % (Ko, smo.nstates), "samples": To,
-                "engine": {1: "strict", 2: "ring", 3: "blocked (pair sweep: pair runs as delays, lanes = phases)"}.get(io["engine"], io["engine"]),
+        sweep = ("pair sweep: pair runs as delays, lanes = phases" if No == 2 else
+                 "multi sweep: one wavefront per template, pair runs as delays, compressed entry FIFOs")
+        return {"model": "N=%d K=%d allow_overlaps=true, %d states" % (No, Ko, smo.nstates), "samples": To,
+                "engine": {1: "strict", 2: "ring", 3: "blocked (%s)" % sweep}.get(io["engine"], io["engine"]),
                 "block": io["block"], "halo": io["halo"], "Msamples_s": To / per / 1e6,
-                "boundary_check_fails": d[0], "max_boundary_spread": d[2], "near_tie_blocks": d[7]}
+                "boundary_check_fails": d[0], "max_boundary_spread": d[2], "near_ties_on_path": d[7]}
     ov = overlap_decode() if (rank == 0 and world == 1 and not args.quick) else None
+    # the largest model the reference's CLI builds (hmmsort.jl:50-54): 4 templates, 21 123 states
+    ov4 = overlap_decode(10_000_000, 4) if (rank == 0 and world == 1 and not args.quick) else None
 
     ms = dt / args.steps * 1e3
     if rank == 0:
@@ -702,7 +706,7 @@ def main():
                        "sum_kernel_ms_per_step": step_ms_kernels,
                        "em_iteration_ms": em_ms, "em_sigma_after_10": em_sigma,
                        "multi_channel": mc, "config4_share": cfg4, "config5_shape": cfg5,
-                       "overlap_decode": ov,
+                       "overlap_decode": ov, "overlap_decode_4_templates": ov4,
                        "diag": diag[:7], "workspace_GB": info["workspace_bytes"] / 1e9,
                        "near_ties": plan.tie_stats(stream)},
         }

@@ -315,8 +315,11 @@ constexpr int bwd_yring(int ft) { return ft <= 2 ? 256 : 512; }
 // tile q holds the 16 NS lags from 16 NS q of every ring, FT tiles hold them all (B is read once per FT MFMAs).
 // rho and y of the last few hundred steps live in two LDS rings of the wave; a super-step of W steps feeds
 // FT W/4 MFMAs (the remainder waits for the next one), and after the last step the copies are drained with zeros.
+#ifndef HS_BWD_W4
+#define HS_BWD_W4 2
+#endif
 template <int N, bool UC, int FT = 0>
-__global__ __launch_bounds__(64, N <= 4 ? 2 : 1) void kw_bwd(WaveGeom g, const WaveConst *__restrict__ cst,
+__global__ __launch_bounds__(64, N <= 4 ? HS_BWD_W4 : 1) void kw_bwd(WaveGeom g, const WaveConst *__restrict__ cst,
                                                             const double *__restrict__ y,
                                                             const double *__restrict__ Rf,
                                                             const double *__restrict__ FA0,
