@@ -279,6 +279,7 @@ __global__ __launch_bounds__(64 * (N + 1)) void multi_vit_block(MultiArgs a)
         CB[lane] = b;                                // CB[0], CB[1] = 0
     }
     for (int i = tid; i < 256; i += 64 * (N + 1)) CT[i] = tab[kMT_CT + i];
+    if (tid < 16) SRC[tid] = 0.0;                   // (slots beyond the last source are read with a -inf constant: keep them finite)
     // virtual entries of the diagonal runs: the pair (m, m) "entered" m-1 samples before w
     for (int i = tid; i < NP * 64; i += 64 * (N + 1)) {
         const int f = i >> 6, mm = (i & 63) + 1;
@@ -323,11 +324,16 @@ __global__ __launch_bounds__(64 * (N + 1)) void multi_vit_block(MultiArgs a)
         while (f >= N - 1 - i) { f -= N - 1 - i; i++; }
         jf_i = i; jf_j = i + 1 + f;
     }
-    const double ja1 = (!track && q >= 1 && q <= N) ? tab[kMT_A + (q - 1) * 64] : 0.0;   // deviation of A_(q-1)(1)
-    const double ja1r = ja1 * rden;
     const double jcc0 = (jon && q > N) ? tab[kMT_J + 2 * (q - N - 1)] : 0.0;
     const int jsid = q == 0 ? 1 : (q <= N ? 1 + (q - 1) * L + L : 1 + N * L + (q - N - 1) * L * L + L * L);   // 1-based id of source q
-    const int jrow = q == 0 ? 0 : (q <= N ? 1 + (q - 1) * L : 1 + N * L + (q - N - 1) * (2 * L - 1));
+    // target role: lane = 4 * target + source group; group g folds the sources g, g + 4, g + 8, (g + 12), then the four
+    // lanes of a target combine (two quad-permute steps); the lane with g = 0 writes the target
+    const int tq = lane >> 2, tg = lane & 3;
+    const bool ton = !track && tq < NT;
+    const double ta1 = (ton && tq >= 1 && tq <= N) ? tab[kMT_A + (tq - 1) * 64] : 0.0, ta1r = ta1 * rden;   // deviation of A_(tq-1)(1)
+    const int trow = tq == 0 ? 0 : (tq <= N ? 1 + (tq - 1) * L : 1 + N * L + (tq - N - 1) * (2 * L - 1));
+    constexpr int NG = (NT + 3) / 4;                 // sources per group
+    auto sidof = [&](int sx) { return sx == 0 ? 1 : (sx <= N ? 1 + (sx - 1) * L + L : 1 + N * L + (sx - N - 1) * L * L + L * L); };
 
     // ---- the first column (flat start, viterbi.jl:55-63 / warm-up) -------------------------
     {
@@ -382,9 +388,33 @@ __global__ __launch_bounds__(64 * (N + 1)) void multi_vit_block(MultiArgs a)
     };
 
     // junction constants of this lane's target: one register row instead of an LDS read per source and sample
-    double ctr[NT];
+    double ctr[NG];
 #pragma unroll
-    for (int sidx = 0; sidx < NT; sidx++) ctr[sidx] = CT[(q < NT ? q : 0) * 16 + sidx];
+    for (int j = 0; j < NG; j++) ctr[j] = (tq < NT && tg + 4 * j < NT) ? CT[tq * 16 + tg + 4 * j] : -INFINITY;
+    // first maximum in list order (lowest source index among equal values), runner-up, arg: this lane's sources, then
+    // the four lanes of the target
+    auto jdecide = [&](double &best, double &sec, int &arg) {
+        best = -INFINITY; sec = -INFINITY; arg = tg;
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            const double v = SRC[(tg + 4 * j) & 15] + ctr[j];
+            const bool gt = v > best;
+            sec = fmax(sec, fmin(best, v));
+            best = fmax(best, v);
+            arg = gt ? tg + 4 * j : arg;
+        }
+#define HS_JQ(CTRL)                                                                              \
+        {                                                                                        \
+            const double ob = dpp_mov<CTRL, 0xF>(best, best), os = dpp_mov<CTRL, 0xF>(sec, sec); \
+            const int oi = __builtin_amdgcn_update_dpp(arg, arg, CTRL, 0xF, 0xF, false);         \
+            const bool take = ob > best || (ob == best && oi < arg);                             \
+            sec = fmax(fmax(os, sec), fmin(ob, best));                                           \
+            best = fmax(ob, best);                                                               \
+            arg = take ? oi : arg;                                                               \
+        }
+        HS_JQ(0xB1) HS_JQ(0x4E)                      // quad_perm [1,0,3,2], [2,3,0,1]
+#undef HS_JQ
+    };
     int e0w = smod(w + 1, L + 1);                   // slot of the diagonal-run FIFOs written at the current sample: t mod (L+1)
     double *myY = YB + wv * 64;
     auto ychunk = [&](int64_t tc) { const int64_t tt = tc + lane; return a.y[tt < e ? tt : e - 1]; };
@@ -428,8 +458,8 @@ __global__ __launch_bounds__(64 * (N + 1)) void multi_vit_block(MultiArgs a)
 #pragma unroll
             for (int cnd = 1; cnd < N; cnd++) {
                 const bool gt = bb[cnd] > best;
-                sec = gt ? best : fmax(sec, bb[cnd]);
-                best = gt ? bb[cnd] : best;
+                sec = fmax(sec, fmin(best, bb[cnd]));
+                best = fmax(best, bb[cnd]);
                 o1 = gt ? cnd : o1;
             }
             int argA = ida;
@@ -446,8 +476,8 @@ __global__ __launch_bounds__(64 * (N + 1)) void multi_vit_block(MultiArgs a)
                 for (int p = 0; p < N - 1; p++) {
                     if (p == qy) continue;
                     const bool gt = bb[p + 1] > wn;
-                    rn = gt ? wn : fmax(rn, bb[p + 1]);
-                    wn = gt ? bb[p + 1] : wn;
+                    rn = fmax(rn, fmin(wn, bb[p + 1]));
+                    wn = fmax(wn, bb[p + 1]);
                     ow = gt ? idx[p] : ow;
                 }
                 argP[qy] = ow | ((wn - rn) < thr ? 0x8000 : 0);
@@ -517,35 +547,23 @@ __global__ __launch_bounds__(64 * (N + 1)) void multi_vit_block(MultiArgs a)
             if (q > N && q < NT)
                 sv = ((E0[(q - N - 1) * 64 + (e0w == L ? 0 : e0w + 1)] + PUB[pp * 32 + 8 + jf_i]) + PUB[pp * 32 + 8 + jf_j]) - jcc0;   // entered at t - L
             if (q < NT) SRC[q] = sv;
-            double best = -INFINITY, sec = -INFINITY;
-            int arg = 0;
-#pragma unroll
-            for (int sidx = 0; sidx < NT; sidx++) {
-                const double v = SRC[sidx] + ctr[sidx];
-                const bool gt = v > best;
-                sec = gt ? best : fmax(sec, v);
-                best = gt ? v : best;
-                arg = gt ? sidx : arg;
-            }
+            double best, sec;
+            int arg;
+            jdecide(best, sec, arg);
             int flag = (best - sec) < thr ? 0x8000 : 0;
-            const double res = best + (2.0 * u - ja1) * ja1r;      // (gain of A_i(1); zero deviation elsewhere)
+            const double res = best + (2.0 * u - ta1) * ta1r;      // (gain of A_i(1); zero deviation elsewhere)
             if (w == 0 && t == 1) {                                // exact first decisions (see the tracks)
                 const double dd = a.y[0] - a.mean[jon ? jsid - 1 : 0];
                 if (q < NT) SRC[q] = q == 0 ? 0.0 : a.c0 - (dd * dd) / a.den;      // T1[1,1] = 0 (viterbi.jl:63)
-                double bv = -INFINITY;
-#pragma unroll
-                for (int sidx = 0; sidx < NT; sidx++) {
-                    const double v = SRC[sidx] + ctr[sidx];
-                    const bool gt = v > bv;
-                    bv = gt ? v : bv;
-                    arg = gt ? sidx : arg;
-                }
+                double bx, sx;
+                jdecide(bx, sx, arg);
                 flag = 0;
             }
-            const int sid = __shfl(jsid, arg);
-            if (own && jon) psi[jrow] = (int16_t)(sid | flag);
-            if (q >= 1 && q <= N) PUB[par * 32 + 16 + (q - 1)] = res;
-            if (q > N && q < NT) E0[(q - N - 1) * 64 + e0w] = res;
+            if (ton && tg == 0) {
+                if (own) psi[trow] = (int16_t)(sidof(arg) | flag);
+                if (tq >= 1 && tq <= N) PUB[par * 32 + 16 + (tq - 1)] = res;
+                if (tq > N) E0[(tq - N - 1) * 64 + e0w] = res;
+            }
             Zv = wave_bcast(res, 0);
             e0w = e0w == L ? 0 : e0w + 1;
         }
