@@ -1134,7 +1134,11 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     }
     if (g->nms >= 64 && S > 1) {
         // wide rows: backtrace by segments (k_seg_walk)
-        const int SEG = 256, WI = (int)std::max<int64_t>(256, 4 * (g->K - 1));
+        // (test aids: HMMSORT_SEG_WI shortens the walk-in so that guesses fail and k_seg_fix has work,
+        // HMMSORT_SEG_PASSES limits the fix passes so that open boundaries reach diag[0])
+        const char *ewi = getenv("HMMSORT_SEG_WI"), *eps = getenv("HMMSORT_SEG_PASSES");
+        const int SEG = 256, WI = ewi ? std::max(1, atoi(ewi)) : (int)std::max<int64_t>(256, 4 * (g->K - 1));
+        const int npass = eps ? std::max(0, std::min(64, atoi(eps))) : 8;
         const int nseg = (int)((T + SEG - 1) / SEG);
         if (!g->d_segbuf) {
             if ((rc = dalloc(&g->d_segbuf, (size_t)2 * nseg + 2, &g->bytes))) return rc;
@@ -1151,11 +1155,11 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
         else hipLaunchKernelGGL(k_seg_walk<false>, gs, dim3(256), 0, st, g->d_T2, g->d_bt, g->nms, T, (int)S, SEG, WI,
                                 nseg, g->d_endstate + (nb - 1), d_x, guess, below);
         HS_HIP(hipGetLastError());
-        for (int pass = 0; pass <= 8; pass++) {
+        for (int pass = 0; pass <= npass; pass++) {
             if (btl) hipLaunchKernelGGL(k_seg_fix<true>, gs, dim3(256), lds_seg, st, g->d_T2, g->d_bt, g->nms, T, (int)S, SEG,
-                                        nseg, d_x, guess, below, pass == 8, g->d_bdiag);
+                                        nseg, d_x, guess, below, pass == npass, g->d_bdiag);
             else hipLaunchKernelGGL(k_seg_fix<false>, gs, dim3(256), 0, st, g->d_T2, g->d_bt, g->nms, T, (int)S, SEG, nseg,
-                                    d_x, guess, below, pass == 8, g->d_bdiag);
+                                    d_x, guess, below, pass == npass, g->d_bdiag);
             HS_HIP(hipGetLastError());
         }
     } else {

@@ -348,12 +348,7 @@ __global__ __launch_bounds__(256) void k_pair_ties(const int16_t *__restrict__ x
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; t < T; t += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)x[t] - 1;
         const int row = bt ? (bt[j] <= 0 ? -bt[j] : -1) : (j < nms ? j : -1);
-        if (row >= 0 && (T2c[t * nms + row] & (int16_t)0x8000)) {
-            n++;
-#ifdef HS_PAIR_DEBUG
-            printf("flag on path: t %lld state %d row %d psi %d prev %d\n", (long long)t, j + 1, row, (int)(T2c[t * nms + row] & 0x7fff), (int)x[t - 1]);
-#endif
-        }
+        if (row >= 0 && (T2c[t * nms + row] & (int16_t)0x8000)) n++;
     }
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(&diag[7], n);
@@ -380,12 +375,7 @@ __global__ __launch_bounds__(256) void k_pair_tail(const double *__restrict__ en
         }
         const double mmax = fabs(c0) * (double)T + qsum[0] / den + fabs(tab[0]) * (double)T + 1.0;
         const double thr = ldexp(16.0 * (double)(L + 2), ilogb(mmax) - 52) + 1e-10;
-        if (best - sec < thr) {
-            atomicAdd(&diag[7], 1ull);
-#ifdef HS_PAIR_DEBUG
-            printf("tail margin %g thr %g best %g\n", best - sec, thr, best);
-#endif
-        }
+        if (best - sec < thr) atomicAdd(&diag[7], 1ull);
     }
 }
 

@@ -316,7 +316,7 @@ constexpr int bwd_yring(int ft) { return ft <= 2 ? 256 : 512; }
 // rho and y of the last few hundred steps live in two LDS rings of the wave; a super-step of W steps feeds
 // FT W/4 MFMAs (the remainder waits for the next one), and after the last step the copies are drained with zeros.
 #ifndef HS_BWD_W4
-#define HS_BWD_W4 2
+#define HS_BWD_W4 2   // waves per SIMD asked of the compiler for up to 4 rings (3, with a one-deep input pipeline and chains of 3 264 samples: 18 spilled registers, 0.382 against 0.369 ms)
 #endif
 template <int N, bool UC, int FT = 0>
 __global__ __launch_bounds__(64, N <= 4 ? HS_BWD_W4 : 1) void kw_bwd(WaveGeom g, const WaveConst *__restrict__ cst,

@@ -390,3 +390,33 @@ def test_multi_sweep_duplicate_templates_fall_back(O, H):
     xo, llo = O.viterbi(y, to_oracle_sm(O, sm), temps, 0.3)
     assert H.get_option("last_escalations") >= 1
     assert np.array_equal(x, xo) and abs(ll - llo) <= LL_RTOL * abs(llo)
+
+
+def test_segment_backtrace_repairs_wrong_guesses(O, H, monkeypatch):
+    # the backtrace by segments (k_seg_walk) guesses each segment's last state from a walk-in; with a walk-in of ONE
+    # sample most guesses inside spikes are wrong and k_seg_fix has to re-walk those segments from the true state:
+    # the path must still be the oracle's, with every boundary consistent (diag[0] == 0)
+    import torch
+    y, sm, mu = _multi_case(H, 3, 20, 40_000, 21)
+    xo, llo = O.viterbi(y, to_oracle_sm(O, sm), mu, 0.3)
+    st = torch.cuda.current_stream().cuda_stream
+    monkeypatch.setenv("HMMSORT_SEG_WI", "1")
+    plan = H.Plan(len(y), sm, mu, 0.3)
+    dy = torch.from_numpy(y).cuda()
+    dx = torch.zeros(len(y), dtype=torch.int16, device="cuda")
+    dll = torch.zeros(1, dtype=torch.float64, device="cuda")
+    plan.viterbi(dy, dx, dll, st)
+    d = plan.diagnostics(st)
+    assert d[0] == 0, d
+    assert np.array_equal(dx.cpu().numpy(), xo)
+    # without fix passes the wrong guesses stay: they must be COUNTED (diag[0]), never silently returned ...
+    monkeypatch.setenv("HMMSORT_SEG_PASSES", "0")
+    plan.viterbi(dy, dx, dll, st)
+    d0 = plan.diagnostics(st)
+    plan.close()
+    assert d0[0] > 0, d0
+    # ... and the host-buffer entry point then falls back to an engine that needs no guess
+    H.set_option("engine", H.ENGINE_AUTO)
+    x, ll = H.viterbi(y, sm, mu, 0.3)
+    assert np.array_equal(x, xo) and abs(ll - llo) <= LL_RTOL * abs(llo)
+    assert H.get_option("last_escalations") >= 1
