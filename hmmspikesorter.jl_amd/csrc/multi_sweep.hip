@@ -238,7 +238,7 @@ size_t multi_lds_bytes(int N, int L)
 {
     const int NP = N * (N - 1) / 2;
     const size_t slots = (size_t)L * (L + 1) / 2 - 1;
-    size_t dbl = (size_t)N * slots * 2 + (size_t)NP * 64 + 64 + 256 + 16 + (size_t)(N + 1) * 64 + (size_t)N * 128;
+    size_t dbl = (size_t)N * slots * 2 + (size_t)NP * 64 + 64 + 256 + 24 + (size_t)(N + 1) * 64 + (size_t)N * 128;
     return dbl * 8 + 64 * 4 + (size_t)N * slots + 64;
 }
 
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(64 * (N + 1)) void multi_vit_block(MultiArgs a)
     double *E0 = FV + (size_t)N * slots * 2;        // NP x 64: diagonal runs P(i:1,j:1), FIFO of L+1 samples
     double *PUB = E0 + NP * 64;                     // 2 parities x 32: dL[i] at 0.., sL[i] at 8.., A1[i] at 16.., Z at 24
     double *CT = PUB + 64;                          // junction constants
-    double *SRC = CT + 256;                         // junction source values
-    double *YB = SRC + 16;                          // N + 1 x 64 samples
+    double *SRC = CT + 256;                         // junction source values (+ one slot that idle lanes write)
+    double *YB = SRC + 24;                          // N + 1 x 64 samples
     double *DS = YB + (N + 1) * 64;                 // dump scratch: d, s of every track
     int *CB = reinterpret_cast<int *>(DS + N * 128);   // CB[d] = first slot of column d (d = 1..L-1)
     unsigned char *FO = reinterpret_cast<unsigned char *>(CB + 64);   // N x slots: owner of the best (0xFF: the single)
@@ -546,7 +546,9 @@ __global__ __launch_bounds__(64 * (N + 1)) void multi_vit_block(MultiArgs a)
             if (q >= 1 && q <= N) sv = PUB[pp * 32 + (q - 1)];
             if (q > N && q < NT)
                 sv = ((E0[(q - N - 1) * 64 + (e0w == L ? 0 : e0w + 1)] + PUB[pp * 32 + 8 + jf_i]) + PUB[pp * 32 + 8 + jf_j]) - jcc0;   // entered at t - L
-            if (q < NT) SRC[q] = sv;
+            // (stores without a lane predicate: under "if (q < NT)" hipcc sank the loads of the reduction below into the
+            // predicated region, and the lanes beyond kept stale operands for the cross-lane steps)
+            SRC[q < NT ? q : 16] = sv;
             double best, sec;
             int arg;
             jdecide(best, sec, arg);
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(64 * (N + 1)) void multi_vit_block(MultiArgs a)
             const double res = best + (2.0 * u - ta1) * ta1r;      // (gain of A_i(1); zero deviation elsewhere)
             if (w == 0 && t == 1) {                                // exact first decisions (see the tracks)
                 const double dd = a.y[0] - a.mean[jon ? jsid - 1 : 0];
-                if (q < NT) SRC[q] = q == 0 ? 0.0 : a.c0 - (dd * dd) / a.den;      // T1[1,1] = 0 (viterbi.jl:63)
+                SRC[q < NT ? q : 16] = q == 0 ? 0.0 : a.c0 - (dd * dd) / a.den;    // T1[1,1] = 0 (viterbi.jl:63)
                 double bx, sx;
                 jdecide(bx, sx, arg);
                 flag = 0;

@@ -420,3 +420,34 @@ def test_segment_backtrace_repairs_wrong_guesses(O, H, monkeypatch):
     x, ll = H.viterbi(y, sm, mu, 0.3)
     assert np.array_equal(x, xo) and abs(ll - llo) <= LL_RTOL * abs(llo)
     assert H.get_option("last_escalations") >= 1
+
+
+@pytest.mark.parametrize("N,first", [(3, 0), (4, 1), (4, 3), (2, 1)])
+def test_overlap_sweeps_first_decisions(O, H, N, first):
+    # a spike that starts at the SECOND sample of a recording: its first state is decided among Z, every A_l(L) and
+    # every P(l:L, l':L) of the first column (emission only, viterbi.jl:55-63), candidates that tie to the last bit;
+    # the structured sweeps take these decisions in the reference's own arithmetic (a fuzz case found lanes of the
+    # junction reduction working on stale operands here: path wrong at sample 1, nothing flagged)
+    import torch
+    K, T, sigma = 24, 6_000, 0.36
+    shapes = [(3.0, 0.8, 0.2), (4.0, 0.3, 0.2), (2.5, 0.6, 0.25), (3.5, 0.5, 0.15)]
+    temps = np.asfortranarray(np.stack([H.create_spike_template(K, *shapes[i]) for i in range(N)], 1))
+    pp = [0.004, 0.006, 0.003, 0.005][:N]
+    sm = H.StateMatrix.create(N, K, np.log(pp), True)
+    st = torch.cuda.current_stream().cuda_stream
+    for y0 in (0.18, 0.05, -0.3):
+        y = H.create_signal(T, sigma, pp, temps, seed=77 + first)
+        y[:K + 2] = 0.01
+        y[0] = y0
+        y[1:K] += temps[1:, first]
+        xo, llo = O.viterbi(y, to_oracle_sm(O, sm), temps, sigma)
+        plan = H.Plan(T, sm, temps, sigma)
+        dx = torch.zeros(T, dtype=torch.int16, device="cuda")
+        dll = torch.zeros(1, dtype=torch.float64, device="cuda")
+        plan.viterbi(torch.from_numpy(y).cuda(), dx, dll, st)
+        d = plan.diagnostics(st)
+        plan.close()
+        x = dx.cpu().numpy()
+        assert d[0] == 0
+        assert d[7] > 0 or np.array_equal(x, xo), (y0, x[:4], xo[:4], d)
+        assert np.array_equal(x[:3], xo[:3]) or d[7] > 0, (y0, x[:4], xo[:4])
