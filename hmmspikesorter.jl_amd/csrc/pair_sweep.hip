@@ -131,15 +131,11 @@ bool pair_analyze(const HostModel &m, std::vector<double> &tab)
 __device__ __forceinline__ double pair_bcast(double v, int lane) { return wave_bcast(v, lane); }
 
 // Skewed entry buffer: an entry of column d (written by lane d of the track that is ahead by d phases) is read
-// L - d steps later, so column d is a FIFO of pairfifo(L, d) = the power of two above L - d slots, addressed by
-// time & (len - 1).  Columns are packed one after the other: 2474 slots per direction at L = 59 instead of a
-// 64 x 64 square -- 39 KB of LDS per wavefront, i.e. four wavefronts per CU instead of two.
-__host__ __device__ inline int pairfifo(int L, int d)
-{
-    int n = 2;
-    while (n < L - d + 1) n <<= 1;
-    return n;
-}
+// L - d steps later, so column d is a FIFO of pairfifo(L, d) = L - d + 1 slots (column 0, silent -> P(1,1): L + 1)
+// addressed by running positions that wrap at the column's own length.  Columns are packed one after the other:
+// 1 829 slots per direction at L = 59 instead of a 64 x 64 square (or 2 474 with power-of-two columns and masks) --
+// 29 KB of LDS per wavefront, i.e. five wavefronts per CU.
+__host__ __device__ inline int pairfifo(int L, int d) { return d == 0 ? L + 1 : L - d + 1; }
 __host__ __device__ inline int pairbase(int L, int d)   // slots of the columns before d (column 0: silent -> P(1,1))
 {
     int b = 0;
@@ -150,10 +146,11 @@ __host__ __device__ inline int pairbase(int L, int d)   // slots of the columns 
 __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
 {
     extern __shared__ double eb[];            // EAB columns 0..L-1 | EBA columns 1..L-1 | 64 samples | column bases
-    const int nAB = pairbase(a.L, a.L), nBA = nAB - pairfifo(a.L, 0), msk0 = pairfifo(a.L, 0) - 1;
+    const int nAB = pairbase(a.L, a.L), nBA = nAB - pairfifo(a.L, 0), n0 = pairfifo(a.L, 0);
+    auto smod = [](int64_t v, int n) { const int r = (int)(v % n); return r < 0 ? r + n : r; };
     double *EAB = eb, *EBA = eb + nAB - pairfifo(a.L, 0);          // EBA[pairbase(d)] is valid for d >= 1
     double *YB = eb + nAB + nBA;
-    int *CB = reinterpret_cast<int *>(YB + 64);                    // CB[d] = base of column d, CB[64 + d] = its mask
+    int *CB = reinterpret_cast<int *>(YB + 64);                    // CB[d] = base of column d, CB[64 + d] = its length
     const int lane = threadIdx.x, c = blockIdx.x, L = a.L, S = a.S;
     const int k = lane + 1;                   // this lane's phase
     const bool on = lane < L;
@@ -180,11 +177,11 @@ __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
     const int idAL = 1 + L, idBL = 1 + 2 * L, idPLL = 1 + 2 * L + L * L;
 
     for (int i = lane; i < nAB + nBA; i += 64) eb[i] = 0.0;
-    if (lane < L) { CB[lane] = pairbase(L, lane); CB[64 + lane] = pairfifo(L, lane) - 1; }
+    if (lane < L) { CB[lane] = pairbase(L, lane); CB[64 + lane] = pairfifo(L, lane); }
     __syncthreads();
     // this lane's columns: it WRITES column k (entries of the pair runs it starts), it READS column L - lane
-    const int wcol = (on && k <= L - 1) ? CB[k] : 0, wmsk = (on && k <= L - 1) ? CB[64 + k] : 0;
-    const int rcol = has_exit ? CB[dex] : 0, rmsk = has_exit ? CB[64 + dex] : 0;
+    const int wcol = (on && k <= L - 1) ? CB[k] : 0, nwr = (on && k <= L - 1) ? CB[64 + k] : 1;
+    const int rcol = has_exit ? CB[dex] : 0, nrd = has_exit ? CB[64 + dex] : 1;
     const int rposb = has_exit ? rcol : CB[1];      // EBA has no column 0
     // per-lane constants of the two-way decisions: first candidate's log-probability, ids of both candidates
     const double c1A_r = lane == 0 ? c0A : cAA, c1B_r = lane == 0 ? c0B : cBB;
@@ -196,9 +193,9 @@ __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
     {
         const int d = lane;
         for (int n = 0; n < L; n++) {
-            if (d == 0) EAB[(int)((w - n) & msk0)] = tab[kPT_P0 + n];
+            if (d == 0) EAB[smod(w - n, n0)] = tab[kPT_P0 + n];
             else if (d <= L - 1 - n) {
-                const int pos = CB[d] + (int)((w - n) & CB[64 + d]);
+                const int pos = CB[d] + smod(w - n, CB[64 + d]);
                 EAB[pos] = tab[kPT_PAB + d * 64 + n];
                 EBA[pos] = tab[kPT_PBA + d * 64 + n];
             }
@@ -223,9 +220,9 @@ __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
             if (on) {
                 const int d = k - k2;
                 double v;
-                if (d > 0) v = EAB[CB[d] + (int)((t - k2 + 1) & CB[64 + d])] - tab[kPT_PAB + d * 64 + k2];
-                else if (d == 0) v = EAB[(int)((t - k2 + 1) & msk0)] - tab[kPT_P0 + k2];
-                else v = EBA[CB[-d] + (int)((t - k + 1) & CB[64 - d])] - tab[kPT_PBA + (-d) * 64 + k];
+                if (d > 0) v = EAB[CB[d] + smod(t - k2 + 1, CB[64 + d])] - tab[kPT_PAB + d * 64 + k2];
+                else if (d == 0) v = EAB[smod(t - k2 + 1, n0)] - tab[kPT_P0 + k2];
+                else v = EBA[CB[-d] + smod(t - k + 1, CB[64 - d])] - tab[kPT_PBA + (-d) * 64 + k];
                 col[2 * L + (k - 1) * L + k2] = (v + sA) + sBk2;
             }
         }
@@ -235,6 +232,8 @@ __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
     // the previous step's back-pointer stores to reach L2 (measured: 0.55 us per step instead of ~0.15)
     auto ychunk = [&](int64_t tc) { const int64_t ti = tc + lane; return a.y[ti < e ? ti : e - 1]; };
     double ynxt = ychunk(w + 1);
+    // running slots of the sample about to be processed (t = w + 1): this lane's write / read column, column 0
+    int wp = smod(w + 1, nwr), rp = smod(w + 1 - lane, nrd), p0w = smod(w + 1, n0);
     for (int64_t tc = w + 1; tc < e; tc += 64) {
       YB[lane] = ynxt;
       ynxt = ychunk(tc + 64 < e ? tc + 64 : tc);
@@ -257,16 +256,16 @@ __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
         const double dAL = pair_bcast(dA, L - 1), dBL = pair_bcast(dB, L - 1);
         const double sAL = pair_bcast(sA, L - 1), sBL = pair_bcast(sB, L - 1);
         // pair runs that end now (entered lane steps ago by lane L-k+1 of the other track)
-        const int rpos = rcol + (((int)t - lane) & rmsk);          // (lanes without an exit read slot 0 of column 0: unused)
-        const double xa = ((EBA[rposb + (((int)t - lane) & rmsk)] + sBL) + psA) - CCba_r;      // P(k-1, L) at t-1
+        const int rpos = rcol + rp;                                // (lanes without an exit read slot 0 of column 0: unused)
+        const double xa = ((EBA[rposb + rp] + sBL) + psA) - CCba_r;      // P(k-1, L) at t-1
         const double xb = ((EAB[rpos] + sAL) + psB) - CCab_r;      // P(L, k-1) at t-1
-        const double xp = ((EAB[(int)((t - L) & msk0)] + sAL) + sBL) - CC0;   // P(L, L) at t-1 (wave-uniform)
+        const double xp = ((EAB[p0w == L ? 0 : p0w + 1] + sAL) + sBL) - CC0;   // P(L, L) at t-1 (wave-uniform; entered at t - L)
         // entries of this sample (from the previous sample's singles)
         if (on && k <= L - 1) {
-            const int wpos = wcol + ((int)t & wmsk);
+            const int wpos = wcol + wp;
             EAB[wpos] = (dA + cAP) - sA; EBA[wpos] = (dB + cBP) - sB;
         }
-        if (lane == 0) EAB[(int)(t & msk0)] = D0 + c0P;
+        if (lane == 0) EAB[p0w] = D0 + c0P;
         // decisions, list order = source index ascending, strict '>' (viterbi.jl:74-84): A_k <- {A_(k-1), P(k-1,L)},
         // A_1 <- {silent, B_L}, B alike (the first candidate's constant and both ids are per-lane registers)
         const double c1a = pdA + c1A_r, c1b = pdB + c1B_r;
@@ -313,6 +312,9 @@ __global__ __launch_bounds__(64) void pair_vit_block(PairArgs a)
         D0 = best;
         dA = nA; dB = nB;
         sA = psA + gA; sB = psB + gB;
+        wp = wp + 1 == nwr ? 0 : wp + 1;
+        rp = rp + 1 == nrd ? 0 : rp + 1;
+        p0w = p0w == L ? 0 : p0w + 1;
         // (LDS operations of one wavefront execute in order: the next sample's reads see this sample's entries)
       }
     }
