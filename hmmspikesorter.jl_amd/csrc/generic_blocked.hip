@@ -1129,9 +1129,14 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
     if (g->nms >= 64 && S > 1) {
         // wide rows: backtrace by segments (k_seg_walk)
         // (test aids: HMMSORT_SEG_WI shortens the walk-in so that guesses fail and k_seg_fix has work,
-        // HMMSORT_SEG_PASSES limits the fix passes so that open boundaries reach diag[0])
+        // HMMSORT_SEG_PASSES limits the fix passes so that open boundaries reach diag[0], HMMSORT_SEG_LEN sets the segment length)
         const char *ewi = getenv("HMMSORT_SEG_WI"), *eps = getenv("HMMSORT_SEG_PASSES");
-        const int SEG = 256, WI = ewi ? std::max(1, atoi(ewi)) : (int)std::max<int64_t>(256, 4 * (g->K - 1));
+        const char *esg = getenv("HMMSORT_SEG_LEN");
+        // long recordings are bound by the walkers' total steps, T (1 + WI / SEG): long segments; a chunk of the CLI's
+        // decode (100 000 samples, fit.jl:11-42) by the steps of ONE walker, SEG + WI: short segments (57 -> 65 Msamples/s)
+        const bool short_sig = T < 2000000;
+        const int SEG = esg ? std::max(16, atoi(esg)) : (short_sig ? 64 : 256);
+        const int WI = ewi ? std::max(1, atoi(ewi)) : (int)std::max<int64_t>(short_sig ? 192 : 256, (short_sig ? 3 : 4) * (g->K - 1) + 16);
         const int npass = eps ? std::max(0, std::min(64, atoi(eps))) : 8;
         const int nseg = (int)((T + SEG - 1) / SEG);
         if (!g->d_segbuf) {
