@@ -1,5 +1,7 @@
-"""Replay of scripts/fuzz_gpu.py up to one case (same RNG draws, no GPU work before it), then the chunked fit of
-that case chunk by chunk against the oracle."""
+"""Replay of ONE case of scripts/fuzz_gpu.py (same RNG draws, no GPU work for the cases before it), then its chunked fit
+chunk by chunk through the plan API, structured and generic sweeps, against the oracle.  This is how the stale-operand bug
+of the multi sweep's junction was located (fuzz_gpu.py 500 31, case 403; DESIGN 5, lesson vii).
+usage: python scripts/fuzz_replay.py <case> <seed>"""
 import os, sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
@@ -65,23 +67,3 @@ while True:
         j -= 1; k -= 1
     if j <= i: break
     i = j
-print("---- detail of chunk 4")
-i0, j0 = 25643, 30804
-seg = y[i0:j0]
-xo, llo = O.viterbi(seg, osm, temps, sigma)
-plan = H.Plan(len(seg), sm, temps, sigma)
-dx = torch.zeros(len(seg), dtype=torch.int16, device="cuda"); dll = torch.zeros(1, dtype=torch.float64, device="cuda")
-plan.viterbi(dX.data_ptr() + i0 * 8, dx, dll, st); torch.cuda.synchronize()
-x = dx.cpu().numpy(); plan.close()
-L = K - 1
-def name(s):
-    s -= 1
-    if s == 0: return "Z"
-    if s <= N * L: return "A%d(%d)" % ((s - 1) // L, (s - 1) % L + 1)
-    s -= 1 + N * L
-    f, r = divmod(s, L * L)
-    fam = [(a, b) for a in range(N) for b in range(a + 1, N)][f]
-    return "P(%d:%d,%d:%d)" % (fam[0], r // L + 1, fam[1], r % L + 1)
-print("x ", [name(int(v)) for v in x[:4]])
-print("xo", [name(int(v)) for v in xo[:4]])
-print("y0", seg[0], "sigma", sigma)
