@@ -33,6 +33,8 @@ for case in range(ONLY + 1):
     if T * S <= 4_000_000 and T >= 2:
         rng.uniform(0.8, 1.2, N)
 print("case", ONLY, "N", N, "K", K, "ov", ov, "S", S, "T", T, "sigma", sigma, "blk", blk, "hal", hal, "cs", cs)
+if cs is None:
+    print("this case has no chunked fit"); sys.exit(0)
 y = H.create_signal(T, sigma, pp, temps, seed=yseed)
 sm = H.StateMatrix.create(N, K, np.log(pp), ov)
 osm = to_oracle_sm(O, sm)
