@@ -61,6 +61,7 @@ SIGNATURES = {
     "hmmsort_plan_set_model_channel": (_int, [_vp, _i64, _vp, _i64, _vp, _f64]),
     "hmmsort_plan_destroy": (_int, [_vp]),
     "hmmsort_plan_info": (_int, [_vp, _pi64, _pi64, _pi64, _pi64, _pi64]),
+    "hmmsort_plan_overlap_sweep": (_i64, [_vp]),
     "hmmsort_plan_bind": (_int, [_vp, _vp, _vp]),
     "hmmsort_plan_unbind": (_int, [_vp]),
     "hmmsort_plan_viterbi": (_int, [_vp, _vp, _vp, _vp, _vp]),

@@ -446,6 +446,11 @@ int hmmsort_plan_info(const hmmsort_plan *p, int64_t *engine, int64_t *block, in
     return HMMSORT_OK;
 }
 
+int64_t hmmsort_plan_overlap_sweep(const hmmsort_plan *p)
+{
+    return (p && p->gen) ? generic_overlap_sweep(p->gen) : 0;
+}
+
 int hmmsort_plan_bind(hmmsort_plan *p, const double *d_y, void *stream)
 {
     HS_CHECK(p && d_y, HMMSORT_EINVAL, "plan_bind: null argument");

@@ -1197,6 +1197,7 @@ int blocked_viterbi(GenericDev *g, const double *d_y, int16_t *d_x, double *d_ll
 }
 
 bool generic_pair_active(const GenericDev *g) { return g && g->blocked && g->pair_ok; }
+int64_t generic_overlap_sweep(const GenericDev *g) { return (g && g->blocked && g->pair_ok) ? (g->multi_ok ? g->N : 2) : 0; }
 void generic_pair_disable(GenericDev *g) { g->pair_off = true; g->pair_ok = false; g->multi_ok = false; }
 
 int blocked_diagnostics(GenericDev *g, hipStream_t st, int64_t diag[8])

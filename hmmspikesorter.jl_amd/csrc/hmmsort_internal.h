@@ -95,6 +95,7 @@ bool generic_is_blocked(const GenericDev *g);
 // switch it off for this plan (host fallback to the generic blocked sweep when a near-tie is flagged on the path)
 bool generic_pair_active(const GenericDev *g);
 void generic_pair_disable(GenericDev *g);
+int64_t generic_overlap_sweep(const GenericDev *g);   // 0 generic sweeps, 2 pair sweep, 3..5 multi sweep
 void generic_geometry(const GenericDev *g, int64_t *block, int64_t *halo, int64_t *nblocks);
 int generic_diagnostics(GenericDev *g, hipStream_t st, int64_t diag[8]);
 int64_t blocked_min_samples();

@@ -78,6 +78,10 @@ class Plan:
         return dict(zip(("engine", "block", "halo", "nchains", "workspace_bytes"),
                         [x.value for x in v]))
 
+    def overlap_sweep(self):
+        """which sweep an overlap model runs on the blocked engine: 0 generic, 2 pair sweep, 3..5 multi sweep"""
+        return int(lib().hmmsort_plan_overlap_sweep(self._h))
+
     def set_model(self, lA, mu, sigma):
         mu = np.asfortranarray(mu, dtype=np.float64)
         tr = np.ascontiguousarray(lA.transitions, dtype=TRANS_DTYPE)

@@ -195,6 +195,10 @@ int hmmsort_plan_destroy(hmmsort_plan *plan);
 /* engine actually used (HMMSORT_ENGINE_STRICT or HMMSORT_ENGINE_RING), geometry, bytes */
 int hmmsort_plan_info(const hmmsort_plan *plan, int64_t *engine, int64_t *block, int64_t *halo,
                       int64_t *nchains, int64_t *workspace_bytes);
+/* Overlap models on the blocked engine: which sweep the plan's current model runs -- 0 the generic sweeps (any
+ * transition list), 2 the two-template sweep (csrc/pair_sweep.hip), 3..5 the multi-template sweep (csrc/multi_sweep.hip);
+ * it follows hmmsort_plan_set_model and drops to 0 when a host entry point fell back.  Other engines: 0. */
+int64_t hmmsort_plan_overlap_sweep(const hmmsort_plan *plan);
 
 /* Optional: compute the signal-dependent intermediates every ring-engine call needs (transposed
  * copy of y and the ring scores of the current model) ONCE and let the following
